@@ -1,0 +1,1015 @@
+// bb_engine.hip -- host side of the C ABI declared in include/barbay_hip.h.
+//
+// Owns device memory, the HIP stream, captured hipGraphs of the step loop, and (optionally) an
+// RCCL communicator.  The compute is the block programs of bb_block.h launched as kernels.
+//
+// Built twice from this one source:
+//   hipcc --offload-arch=gfx950           -> libbarbay_hip.so   (the product)
+//   g++ -DBB_EMU -x c++                   -> tests/_emu/libbb_emu.so (sequential host emulation of
+//                                            the same block programs; test-only debugging aid)
+#include "../../include/barbay_hip.h"
+#include "bb_block.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifndef BB_EMU
+#include <dlfcn.h>
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int bb_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* bb_last_error(void) { return g_err; }
+extern "C" const char* bb_version(void) {
+#ifdef BB_EMU
+    return "barbay_hip 0.1 (host emulation, tests only)";
+#else
+    return "barbay_hip 0.1 (gfx950)";
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// backend: device memory + kernel launches
+// ------------------------------------------------------------------------------------------------
+#ifdef BB_EMU
+typedef int bbStream;
+#define BB_CHECK(x) (x)
+static int dmalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : BB_ERR_DEVICE; }
+static void dfree(void* p) { free(p); }
+static int h2d(void* d, const void* h, size_t n, bbStream) { memcpy(d, h, n); return 0; }
+static int d2h(void* h, const void* d, size_t n, bbStream) { memcpy(h, d, n); return 0; }
+static int d2d(void* d, const void* s, size_t n, bbStream) { memcpy(d, s, n); return 0; }
+static int dzero(void* d, size_t n, bbStream) { memset(d, 0, n); return 0; }
+static int dsync(bbStream) { return 0; }
+template <class F>
+static void emu_launch(int nblocks, int nthr, size_t lds_doubles, F f) {
+    std::vector<double> lds(lds_doubles + 64);
+    for (int b = 0; b < nblocks; ++b) {
+        BBCtx cx{nthr, b, lds.data()};
+        f(cx);
+    }
+}
+#else
+typedef hipStream_t bbStream;
+#define BB_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) return bb_fail(BB_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+static int dmalloc(void** p, size_t n) { BB_HIP(hipMalloc(p, n ? n : 1)); return 0; }
+static void dfree(void* p) { (void)hipFree(p); }
+static int h2d(void* d, const void* h, size_t n, bbStream s) {
+    BB_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
+    BB_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+static int d2h(void* h, const void* d, size_t n, bbStream s) {
+    BB_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+    BB_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+static int d2d(void* d, const void* s_, size_t n, bbStream s) {
+    BB_HIP(hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+static int dzero(void* d, size_t n, bbStream s) { BB_HIP(hipMemsetAsync(d, 0, n, s)); return 0; }
+static int dsync(bbStream s) { BB_HIP(hipStreamSynchronize(s)); return 0; }
+
+extern __shared__ __attribute__((aligned(16))) double bb_smem[];
+
+__global__ void __launch_bounds__(256) k_sample(DevModel M, DevState S, RunArgs A, int NB) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_sample(cx, M, S, A, NB);
+}
+__global__ void __launch_bounds__(256) k_update(DevModel M, DevState S, RunArgs A, int NB) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_update(cx, M, S, A, NB);
+}
+__global__ void __launch_bounds__(256) k_geno(DevModel M, DevState S, RunArgs A, int do_update, int do_sample, int upd_par) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_geno(cx, M, S, A, (int)gridDim.x, do_update, do_sample, upd_par);
+}
+__global__ void __launch_bounds__(256) k_geno_sum(DevModel M, DevState S, long long m_lo, long long m_hi) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_geno_sum(cx, M, S, (int)gridDim.x, m_lo, m_hi);
+}
+__global__ void __launch_bounds__(256) k_reduce(DevModel M, DevState S, int nblk, int ngeno_blocks) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_reduce(cx, M, S, nblk, ngeno_blocks);
+}
+__global__ void __launch_bounds__(256) k_init(DevModel M, DevState S, unsigned long long seed) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_init(cx, M, S, seed, (int)gridDim.x);
+}
+__global__ void __launch_bounds__(256) k_normals(unsigned long long seed, unsigned step, unsigned stream, long long lo,
+                                                 long long hi, double* out) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_normals(cx, seed, step, stream, lo, hi, out, (int)gridDim.x);
+}
+
+// ---- RCCL, bound at run time so that the library loads (and N = 1 runs) without it -------------
+typedef struct { char internal[128]; } bb_ncclUniqueId;
+typedef void* bb_ncclComm_t;
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(bb_ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(bb_ncclComm_t*, int, bb_ncclUniqueId, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, bb_ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(bb_ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return bb_fail(BB_ERR_COMM, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(bb_ncclUniqueId*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(bb_ncclComm_t*, int, bb_ncclUniqueId, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, bb_ncclComm_t, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(bb_ncclComm_t))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return bb_fail(BB_ERR_COMM, "librccl lacks a required symbol");
+    return 0;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct bb_handle {
+    DevModel M{};
+    DevState S{};
+    bb_advi_opts o{};
+    std::vector<bb_block_range> blocks;
+    std::vector<void*> owned;          // device allocations
+    int NB = 0, nthr = 0, nblk = 0, ngeno_blk = 0;
+    size_t lds_doubles = 0;
+    long long b_lo = 0, b_hi = 0;      // barcode shard
+    long long step = 0;                // host mirror of the device step counter
+    int sample = 0;                    // next MC sample inside the current step (split-phase API)
+    double elbo_const = 0.0;
+    double* bak_mu = nullptr;          // bb_elbo_grad: saved parameters
+    double* bak_om = nullptr;
+    double* eps_buf = nullptr;         // device copy of caller-supplied draws
+    size_t eps_cap = 0;
+    double* dbg_buf = nullptr;
+    size_t dbg_cap = 0;
+    bbStream stream{};
+    double last_run_ms = 0, avg_sample_ms = 0, avg_update_ms = 0;
+    int64_t bytes_sample = 0, bytes_update = 0;
+#ifndef BB_EMU
+    hipGraphExec_t graph = nullptr;
+    int graph_steps = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bb_ncclComm_t comm = nullptr;
+#endif
+    bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE; }
+};
+
+template <class T>
+static int dalloc(bb_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    int rc = dmalloc(&q, count * sizeof(T));
+    if (rc) return rc;
+    h->owned.push_back(q);
+    *p = (T*)q;
+    return dzero(q, count * sizeof(T), h->stream);
+}
+
+extern "C" void bb_default_opts(bb_advi_opts* o) {
+    memset(o, 0, sizeof *o);
+    o->samples_per_step = 1;
+    o->optimizer = BB_OPT_TRUNCATED_ADAGRAD;
+    o->eta = 0.1;
+    o->tau = 40.0;
+    o->window = 100;
+    o->resum_every = 0;
+    o->pre = 1.0;
+    o->post = 0.9;
+    o->seed = 0;
+    o->device = 0;
+    o->rank = 0;
+    o->world_size = 1;
+    o->steps_per_graph = 0;
+    o->elbo_every = 0;
+}
+
+static void add_block(bb_handle* h, const char* name, int kind, long long n, long long* off) {
+    bb_block_range b;
+    memset(&b, 0, sizeof b);
+    snprintf(b.name, sizeof b.name, "%s", name);
+    b.lo = *off;
+    b.hi = *off + n;
+    h->blocks.push_back(b);
+    h->M.blk_lo[kind] = b.lo;
+    h->M.blk_hi[kind] = b.hi;
+    *off += n;
+}
+
+static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean, double dstd, const char* name,
+                        bool vector_only, double* sum_log_std) {
+    const long long n = h->M.blk_hi[kind] - h->M.blk_lo[kind];
+    DevPrior& dp = h->M.pri[kind];
+    dp.mean_e = nullptr;
+    dp.inv_var_e = nullptr;
+    if (!p || !p->mean || !p->std || p->n == 0) {
+        dp.mean = dmean;
+        dp.inv_var = 1.0 / (dstd * dstd);
+        *sum_log_std += (double)n * log(dstd);
+        return 0;
+    }
+    if (p->n == 1 || (n == 1 && p->n == 1)) {
+        if (!(p->std[0] > 0)) return bb_fail(BB_ERR_INVALID, "%s: std must be > 0", name);
+        dp.mean = p->mean[0];
+        dp.inv_var = 1.0 / (p->std[0] * p->std[0]);
+        *sum_log_std += (double)n * log(p->std[0]);
+        return 0;
+    }
+    if (vector_only) return bb_fail(BB_ERR_INVALID, "%s accepts only the Vector form [mean, std]", name);
+    if (p->n != n) return bb_fail(BB_ERR_INVALID, "%s: Matrix form needs %lld rows, got %lld", name, n, (long long)p->n);
+    std::vector<double> iv((size_t)n);
+    for (long long i = 0; i < n; ++i) {
+        if (!(p->std[i] > 0)) return bb_fail(BB_ERR_INVALID, "%s: std[%lld] must be > 0", name, i);
+        iv[(size_t)i] = 1.0 / (p->std[i] * p->std[i]);
+        *sum_log_std += log(p->std[i]);
+    }
+    double *dm = nullptr, *di = nullptr;
+    int rc;
+    if ((rc = dalloc(h, &dm, (size_t)n))) return rc;
+    if ((rc = dalloc(h, &di, (size_t)n))) return rc;
+    if ((rc = h2d(dm, p->mean, (size_t)n * 8, h->stream))) return rc;
+    if ((rc = h2d(di, iv.data(), (size_t)n * 8, h->stream))) return rc;
+    dp.mean = 0;
+    dp.inv_var = 0;
+    dp.mean_e = dm;
+    dp.inv_var_e = di;
+    return 0;
+}
+
+static size_t lds_bytes_for(const DevModel& M, int NB) {
+    return (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, NB).total * sizeof(double);
+}
+
+extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
+    if (!md || !opts || !out) return bb_fail(BB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (md->kind < 0 || md->kind > 3) return bb_fail(BB_ERR_INVALID, "unknown model kind %d", md->kind);
+    if (md->n_rep < 1 || md->n_rep > BB_MAX_REP) return bb_fail(BB_ERR_INVALID, "n_rep must be in 1..%d", BB_MAX_REP);
+    if (md->kind != BB_MODEL_REPLICATE && md->n_rep != 1)
+        return bb_fail(BB_ERR_INVALID, "only replicate_fitness_normal takes n_rep > 1");
+    if (md->n_neutral < 1 || md->n_bc < 1) return bb_fail(BB_ERR_INVALID, "need at least one neutral and one mutant barcode");
+    if (!md->n_time || !md->counts || !md->totals) return bb_fail(BB_ERR_INVALID, "n_time/counts/totals missing");
+    if (opts->samples_per_step < 1) return bb_fail(BB_ERR_INVALID, "samples_per_step must be >= 1");
+    if (opts->optimizer != BB_OPT_TRUNCATED_ADAGRAD && opts->optimizer != BB_OPT_DECAYED_ADAGRAD)
+        return bb_fail(BB_ERR_INVALID, "unknown optimizer %d", opts->optimizer);
+    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD && opts->window < 1) return bb_fail(BB_ERR_INVALID, "window must be >= 1");
+    if (opts->world_size < 1 || opts->rank < 0 || opts->rank >= opts->world_size)
+        return bb_fail(BB_ERR_INVALID, "bad rank/world_size %d/%d", opts->rank, opts->world_size);
+
+    bb_handle* h = new bb_handle();
+    h->o = *opts;
+    if (h->o.resum_every <= 0) h->o.resum_every = h->o.window > 0 ? h->o.window : 1;
+    DevModel& M = h->M;
+    M.kind = md->kind;
+    M.R = md->n_rep;
+    M.E = md->kind == BB_MODEL_MULTIENV ? md->n_env : 1;
+    M.G = md->kind == BB_MODEL_GENOTYPE ? md->n_geno : 0;
+    M.nn = md->n_neutral;
+    M.nb = md->n_bc;
+    M.B = M.nn + M.nb;
+    int rc = 0;
+#define BB_TRY(x)                  \
+    do {                           \
+        rc = (x);                  \
+        if (rc) { bb_destroy(h); return rc; } \
+    } while (0)
+
+#ifndef BB_EMU
+    {
+        hipError_t e = hipSetDevice(opts->device);
+        if (e != hipSuccess) { delete h; return bb_fail(BB_ERR_DEVICE, "hipSetDevice(%d): %s", opts->device, hipGetErrorString(e)); }
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return bb_fail(BB_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        (void)hipEventCreate(&h->ev0);
+        (void)hipEventCreate(&h->ev1);
+    }
+#endif
+
+    // ---- shapes -----------------------------------------------------------------------------
+    long long n_l = 0, cnt = 0;
+    M.Ttot = 0; M.nt1 = 0; M.K = 0;
+    for (int r = 0; r < M.R; ++r) {
+        const int T = md->n_time[r];
+        if (T < 2 || T > 255) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "n_time[%d] = %d outside 2..255", r, T); }
+        M.T[r] = T;
+        M.Tmagic[r] = (unsigned)(0x100000000ull / (unsigned)T) + 1u;
+        M.Tmagic1[r] = (unsigned)(0x100000000ull / (unsigned)(T - 1)) + 1u;
+        M.off_t[r] = M.nt1;
+        M.cnt_off[r] = cnt;
+        M.kq[r] = M.K;
+        M.tcum[r] = M.Ttot;
+        M.Ttot += T;
+        M.nt1 += T - 1;
+        M.K += 6 * T - 5;
+        n_l += (long long)T * M.B;
+        cnt += (long long)T * M.B;
+    }
+    M.K += 2;
+    if (md->kind == BB_MODEL_MULTIENV) {
+        if (md->n_env < 1 || !md->env_idx) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "multienv needs n_env >= 1 and env_idx"); }
+        for (int t = 0; t < M.T[0]; ++t)
+            if (md->env_idx[t] < 0 || md->env_idx[t] >= md->n_env) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "env_idx[%d] out of range", t); }
+    }
+    if (md->kind == BB_MODEL_GENOTYPE) {
+        if (md->n_geno < 1 || !md->geno_idx) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "genotype model needs n_geno >= 1 and geno_idx"); }
+        for (long long m = 0; m < M.nb; ++m)
+            if (md->geno_idx[m] < 0 || md->geno_idx[m] >= md->n_geno) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "geno_idx[%lld] out of range", m); }
+    }
+
+    // ---- flat layout, source order (model_*.jl `~` statements) -----------------
+    long long off = 0;
+    for (int k = 0; k < BK_COUNT; ++k) M.blk_lo[k] = M.blk_hi[k] = 0;
+    add_block(h, "s_pop", BK_SPOP, M.nt1, &off);
+    add_block(h, "logsigma_pop", BK_LSPOP, M.nt1, &off);
+    if (M.kind == BB_MODEL_FITNESS || M.kind == BB_MODEL_MULTIENV) {
+        add_block(h, "s_bc", BK_S, M.nb * M.E, &off);
+        add_block(h, "logsigma_bc", BK_LS, M.nb * M.E, &off);
+    } else {
+        add_block(h, "theta", BK_S, M.kind == BB_MODEL_GENOTYPE ? M.G : M.nb, &off);
+        add_block(h, "theta_tilde", BK_TT, M.nb * M.R, &off);
+        add_block(h, "logtau", BK_LT, M.nb * M.R, &off);
+        add_block(h, "logsigma_bc", BK_LS, M.nb * M.R, &off);
+    }
+    add_block(h, "loglambda", BK_L, n_l, &off);
+    M.D = off;
+    for (int r = 0, o = 0; r < M.R; ++r) { M.off_l[r] = M.blk_lo[BK_L] + (long long)o * M.B; o += M.T[r]; }
+
+    // ---- counts: validate totals == row sums (Multinomial support, Distributions.jl), to uint32
+    std::vector<unsigned> c32((size_t)cnt);
+    double sum_lgamma = 0.0;
+    {
+        long long co = 0, to = 0;
+        for (int r = 0; r < M.R; ++r) {
+            const int T = M.T[r];
+            for (int t = 0; t < T; ++t) {
+                long long s = 0;
+                for (long long b = 0; b < M.B; ++b) {
+                    const int64_t v = md->counts[co + b * T + t];
+                    if (v < 0 || v > 0xFFFFFFFFll) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "count out of range at rep %d t %d barcode %lld", r, t, b); }
+                    c32[(size_t)(co + b * T + t)] = (unsigned)v;
+                    s += v;
+                    sum_lgamma += lgamma((double)v + 1.0);
+                }
+                if (s != md->totals[to + t]) {
+                    bb_destroy(h);
+                    return bb_fail(BB_ERR_INVALID, "totals[rep %d, t %d] = %lld but the counts sum to %lld (the reference's Multinomial term is -Inf there)",
+                                   r, t, (long long)md->totals[to + t], s);
+                }
+            }
+            co += (long long)T * M.B;
+            to += T;
+        }
+    }
+    unsigned* dcounts = nullptr;
+    BB_TRY(dalloc(h, &dcounts, (size_t)cnt));
+    BB_TRY(h2d(dcounts, c32.data(), (size_t)cnt * 4, h->stream));
+    M.counts = dcounts;
+
+    if (md->kind == BB_MODEL_MULTIENV) {
+        int* d = nullptr;
+        BB_TRY(dalloc(h, &d, (size_t)M.T[0]));
+        BB_TRY(h2d(d, md->env_idx, (size_t)M.T[0] * 4, h->stream));
+        M.env_idx = d;
+    }
+    if (md->kind == BB_MODEL_GENOTYPE) {
+        int *d = nullptr, *dp = nullptr, *dm = nullptr;
+        BB_TRY(dalloc(h, &d, (size_t)M.nb));
+        BB_TRY(h2d(d, md->geno_idx, (size_t)M.nb * 4, h->stream));
+        M.geno_idx = d;
+        std::vector<int> ptr((size_t)M.G + 1, 0), mem((size_t)M.nb);
+        for (long long m = 0; m < M.nb; ++m) ptr[(size_t)md->geno_idx[m] + 1]++;
+        for (int g = 0; g < M.G; ++g) ptr[(size_t)g + 1] += ptr[(size_t)g];
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+        for (long long m = 0; m < M.nb; ++m) mem[(size_t)fill[(size_t)md->geno_idx[m]]++] = (int)m;
+        BB_TRY(dalloc(h, &dp, (size_t)M.G + 1));
+        BB_TRY(dalloc(h, &dm, (size_t)M.nb));
+        BB_TRY(h2d(dp, ptr.data(), ((size_t)M.G + 1) * 4, h->stream));
+        BB_TRY(h2d(dm, mem.data(), (size_t)M.nb * 4, h->stream));
+        M.geno_ptr = dp;
+        M.geno_mem = dm;
+    }
+
+    // ---- priors (defaults: model_fitness_normal.jl:125-129, ..._genotypes.jl:162) -------------
+    double sum_log_std = 0.0;
+    BB_TRY(upload_prior(h, BK_SPOP, &md->s_pop_prior, 0.0, 2.0, "s_pop_prior", false, &sum_log_std));
+    BB_TRY(upload_prior(h, BK_LSPOP, &md->logsigma_pop_prior, 0.0, 1.0, "logsigma_pop_prior", false, &sum_log_std));
+    BB_TRY(upload_prior(h, BK_S, &md->s_bc_prior, 0.0, 2.0, "s_bc_prior", false, &sum_log_std));
+    BB_TRY(upload_prior(h, BK_LS, &md->logsigma_bc_prior, 0.0, 1.0, "logsigma_bc_prior", false, &sum_log_std));
+    BB_TRY(upload_prior(h, BK_L, &md->loglambda_prior, 3.0, 3.0, "loglambda_prior", false, &sum_log_std));
+    if (M.kind >= BB_MODEL_GENOTYPE) {
+        BB_TRY(upload_prior(h, BK_TT, nullptr, 0.0, 1.0, "theta_tilde", true, &sum_log_std));
+        BB_TRY(upload_prior(h, BK_LT, &md->logtau_prior, -2.0, 1.0, "logtau_prior", true, &sum_log_std));
+    }
+    // constant part of the ELBO: prior normalisers, likelihood normalisers, lgamma terms, entropy constant
+    {
+        double nlik = 0.0;
+        for (int r = 0; r < M.R; ++r) nlik += (double)(M.T[r] - 1) * (double)M.B;
+        h->elbo_const = -sum_log_std - 0.5 * BB_LOG2PI * (double)M.D - sum_lgamma - 0.5 * BB_LOG2PI * nlik +
+                        0.5 * (double)M.D * (1.0 + BB_LOG2PI);
+    }
+
+    // ---- shard + launch geometry -------------------------------------------------------------
+    h->b_lo = M.B * opts->rank / opts->world_size;
+    h->b_hi = M.B * (opts->rank + 1) / opts->world_size;
+    {
+        int maxT = 0;
+        for (int r = 0; r < M.R; ++r) maxT = std::max(maxT, M.T[r]);
+        int NB = 256;
+        while (NB > 64 && lds_bytes_for(M, NB) > 64 * 1024) NB >>= 1;
+        while (NB < maxT) NB <<= 1;
+        if (lds_bytes_for(M, NB) > 160 * 1024 || (long long)NB * maxT >= 65536) {
+            bb_destroy(h);
+            return bb_fail(BB_ERR_UNSUPPORTED, "tile of %d barcodes needs %zu bytes of LDS (n_time too large for this build)", NB, lds_bytes_for(M, NB));
+        }
+        h->NB = NB;
+        h->nthr = NB;
+        h->lds_doubles = lds_bytes_for(M, NB) / 8;
+        h->nblk = (int)((h->b_hi - h->b_lo + NB - 1) / NB);
+        if (h->nblk < 1) h->nblk = 1;
+        h->ngeno_blk = M.G > 0 ? (int)std::min<long long>(((M.G + 1) / 2 + 255) / 256, 64) : 0;
+#ifndef BB_EMU
+        if (h->lds_doubles * 8 > 64 * 1024) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)k_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->lds_doubles * 8));
+            hipError_t e2 = hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->lds_doubles * 8));
+            if (e1 != hipSuccess || e2 != hipSuccess) { bb_destroy(h); return bb_fail(BB_ERR_DEVICE, "cannot raise dynamic LDS to %zu bytes", h->lds_doubles * 8); }
+        }
+#endif
+    }
+
+    // ---- state ---------------------------------------------------------------------------------
+    DevState& S = h->S;
+    const size_t D = (size_t)M.D;
+    BB_TRY(dalloc(h, &S.mu, D + 2));
+    BB_TRY(dalloc(h, &S.om, D + 2));
+    BB_TRY(dalloc(h, &S.eps, D + 2));
+    BB_TRY(dalloc(h, &S.sp, D + 2));
+    BB_TRY(dalloc(h, &S.sig, D + 2));
+    BB_TRY(dalloc(h, &S.acc_mu, D + 2));
+    BB_TRY(dalloc(h, &S.acc_om, D + 2));
+    BB_TRY(dalloc(h, &S.gacc_mu, D + 2));
+    BB_TRY(dalloc(h, &S.gacc_om, D + 2));
+    BB_TRY(dalloc(h, &h->bak_mu, D + 2));
+    BB_TRY(dalloc(h, &h->bak_om, D + 2));
+    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * D));
+    BB_TRY(dalloc(h, &S.partials, (size_t)M.K * (size_t)h->nblk));
+    BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
+    BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
+    BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
+    BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
+    BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));
+    BB_TRY(dalloc(h, &S.geno_el, (size_t)std::max(h->ngeno_blk, 1)));
+    BB_TRY(dalloc(h, &S.elbo_ring, (size_t)BB_ELBO_RING));
+    BB_TRY(dalloc(h, &S.elbo_sample, (size_t)opts->samples_per_step + 64));
+    BB_TRY(dalloc(h, &S.ctr, (size_t)2));
+    S.eps_in = nullptr;
+
+    // algorithmic bytes per step on this shard: theta r+w, optimiser state r+w, counts
+    {
+        const long long nb_sh = h->b_hi - h->b_lo;
+        double frac = (double)nb_sh / (double)M.B;
+        const double Dsh = (double)M.D * frac;
+        const double cnts = 4.0 * (double)cnt * frac;
+        h->bytes_sample = (int64_t)(16.0 * Dsh + cnts);
+        const double optb = opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD ? 64.0 : 32.0;
+        h->bytes_update = (int64_t)((16.0 + 16.0 + optb) * Dsh + cnts);
+    }
+    BB_TRY(bb_init_meanfield(h));
+    *out = h;
+    return BB_OK;
+}
+
+extern "C" void bb_destroy(bb_handle* h) {
+    if (!h) return;
+#ifndef BB_EMU
+    (void)hipStreamSynchronize(h->stream);
+    if (h->graph) (void)hipGraphExecDestroy(h->graph);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+#endif
+    for (void* p : h->owned) dfree(p);
+    if (h->eps_buf) dfree(h->eps_buf);
+    if (h->dbg_buf) dfree(h->dbg_buf);
+#ifndef BB_EMU
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+#endif
+    delete h;
+}
+
+extern "C" int64_t bb_num_latents(const bb_handle* h) { return h ? h->M.D : 0; }
+
+extern "C" int bb_get_layout(const bb_handle* h, bb_block_range* blocks, int32_t* n) {
+    if (!h || !blocks || !n) return bb_fail(BB_ERR_INVALID, "null argument");
+    *n = (int32_t)h->blocks.size();
+    for (size_t i = 0; i < h->blocks.size(); ++i) blocks[i] = h->blocks[i];
+    return BB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo) {
+    RunArgs A;
+    memset(&A, 0, sizeof A);
+    A.b_lo = h->b_lo;
+    A.b_hi = h->b_hi;
+    A.nblk = h->nblk;
+    A.par = (int)(step & 1);
+    A.sample = sample;
+    A.S = S;
+    A.first_sample = sample == 0;
+    A.last_sample = sample == S - 1;
+    A.apply = apply ? 1 : 0;
+    A.with_elbo = with_elbo ? 1 : 0;
+    A.count_globals = h->o.rank == 0;
+    A.opt = h->o.optimizer;
+    A.W = h->o.window;
+    A.resum_every = h->o.resum_every;
+    A.elbo_every = h->o.elbo_every;
+    A.eta = h->o.eta;
+    A.tau = h->o.tau;
+    A.pre = h->o.pre;
+    A.post = h->o.post;
+    A.seed = h->o.seed;
+    A.elbo_const = h->elbo_const;
+    if (h->use_reduce()) { A.red = h->S.totals; A.nred = 1; }
+    else { A.red = h->S.partials; A.nred = h->nblk; }
+    return A;
+}
+
+#ifdef BB_EMU
+#define LAUNCH_CHECK() 0
+#else
+static int launch_check() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bb_fail(BB_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+    return 0;
+}
+#define LAUNCH_CHECK() launch_check()
+#endif
+
+static int launch_sample(bb_handle* h, const RunArgs& A) {
+#ifdef BB_EMU
+    emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) { bb_block_sample(cx, h->M, h->S, A, h->NB); });
+#else
+    hipLaunchKernelGGL(k_sample, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
+#endif
+    return LAUNCH_CHECK();
+}
+static int launch_update(bb_handle* h, const RunArgs& A) {
+#ifdef BB_EMU
+    emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) { bb_block_update(cx, h->M, h->S, A, h->NB); });
+#else
+    hipLaunchKernelGGL(k_update, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
+#endif
+    return LAUNCH_CHECK();
+}
+static int launch_reduce(bb_handle* h) {
+#ifdef BB_EMU
+    emu_launch(1, 256, 0, [&](BBCtx& cx) { bb_block_reduce(cx, h->M, h->S, h->nblk, h->ngeno_blk); });
+#else
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, h->M, h->S, h->nblk, h->ngeno_blk);
+#endif
+    return LAUNCH_CHECK();
+}
+static int launch_geno(bb_handle* h, const RunArgs& A, int do_update, int do_sample, int upd_par) {
+#ifdef BB_EMU
+    emu_launch(h->ngeno_blk, 256, 256 + 64, [&](BBCtx& cx) { bb_block_geno(cx, h->M, h->S, A, h->ngeno_blk, do_update, do_sample, upd_par); });
+#else
+    hipLaunchKernelGGL(k_geno, dim3(h->ngeno_blk), dim3(256), (256 + 64) * 8, h->stream, h->M, h->S, A, do_update, do_sample, upd_par);
+#endif
+    return LAUNCH_CHECK();
+}
+static int launch_geno_sum(bb_handle* h) {
+    const long long m_lo = std::max(h->b_lo, h->M.nn) - h->M.nn, m_hi = std::max(h->b_hi, h->M.nn) - h->M.nn;
+#ifdef BB_EMU
+    emu_launch(h->ngeno_blk, 256, 0, [&](BBCtx& cx) { bb_block_geno_sum(cx, h->M, h->S, h->ngeno_blk, m_lo, m_hi); });
+#else
+    hipLaunchKernelGGL(k_geno_sum, dim3(h->ngeno_blk), dim3(256), 0, h->stream, h->M, h->S, m_lo, m_hi);
+#endif
+    return LAUNCH_CHECK();
+}
+
+static int allreduce(bb_handle* h, double* buf, size_t n) {
+    if (h->o.world_size == 1) return 0;
+#ifdef BB_EMU
+    (void)buf; (void)n;
+    return bb_fail(BB_ERR_COMM, "in-library collectives are not available in the emulation build");
+#else
+    if (!h->comm) return bb_fail(BB_ERR_COMM, "world_size = %d but bb_comm_init was not called (or use bb_step_moments/bb_step_apply)", h->o.world_size);
+    int rc = g_rccl.AllReduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    if (rc) return bb_fail(BB_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    return 0;
+#endif
+}
+
+// first half of one MC sample: draw + moments (+ reduce to totals when sharded / genotype)
+static int sample_half(bb_handle* h, const RunArgs& A) {
+    int rc;
+    if (h->M.kind == BB_MODEL_GENOTYPE && (rc = launch_geno(h, A, 0, 1, 0))) return rc;
+    if ((rc = launch_sample(h, A))) return rc;
+    if (h->use_reduce() && (rc = launch_reduce(h))) return rc;
+    return 0;
+}
+// second half: gradient + update (+ the genotype block's exchange and update)
+static int update_half(bb_handle* h, const RunArgs& A) {
+    int rc;
+    if ((rc = launch_update(h, A))) return rc;
+    if (h->M.kind == BB_MODEL_GENOTYPE) {
+        if ((rc = launch_geno_sum(h))) return rc;
+        if ((rc = allreduce(h, h->S.gsum, (size_t)h->M.G))) return rc;
+        if ((rc = launch_geno(h, A, 1, 0, A.par))) return rc;
+    }
+    return 0;
+}
+
+static bool elbo_wanted(const bb_handle* h, long long step) {
+    return h->o.elbo_every > 0 && step % h->o.elbo_every == 0;
+}
+
+static int enqueue_step(bb_handle* h, long long step) {
+    const int S = h->o.samples_per_step;
+    int rc;
+    for (int s = 0; s < S; ++s) {
+        RunArgs A = make_args(h, step, s, S, true, elbo_wanted(h, step));
+        if ((rc = sample_half(h, A))) return rc;
+        if ((rc = allreduce(h, h->S.totals, (size_t)h->M.K))) return rc;
+        if ((rc = update_half(h, A))) return rc;
+    }
+    return 0;
+}
+
+static int set_step(bb_handle* h, long long step) {
+    unsigned long long c[2] = {(unsigned long long)step, (unsigned long long)step};
+    h->step = step;
+    h->sample = 0;
+    return h2d(h->S.ctr, c, sizeof c, h->stream);
+}
+
+static int reset_optimizer(bb_handle* h) {
+    const size_t D = (size_t)h->M.D;
+    int rc;
+    if (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD) {
+        if ((rc = dzero(h->S.hist, (size_t)h->o.window * 2 * D * 8, h->stream))) return rc;
+        if ((rc = dzero(h->S.acc_mu, D * 8, h->stream))) return rc;
+        if ((rc = dzero(h->S.acc_om, D * 8, h->stream))) return rc;
+    } else {
+        std::vector<double> a(D, 1e-8);   // AdvancedVI: acc = fill(1e-8, size(x))
+        if ((rc = h2d(h->S.acc_mu, a.data(), D * 8, h->stream))) return rc;
+        if ((rc = h2d(h->S.acc_om, a.data(), D * 8, h->stream))) return rc;
+    }
+    std::vector<double> nanv(BB_ELBO_RING, NAN);
+    if ((rc = h2d(h->S.elbo_ring, nanv.data(), nanv.size() * 8, h->stream))) return rc;
+    return set_step(h, 0);
+}
+
+extern "C" int bb_init_meanfield(bb_handle* h) {
+    if (!h) return bb_fail(BB_ERR_INVALID, "null handle");
+    const int nb = (int)std::min<long long>(((h->M.D + 1) / 2 + 255) / 256, 1024);
+#ifdef BB_EMU
+    emu_launch(nb, 256, 0, [&](BBCtx& cx) { bb_block_init(cx, h->M, h->S, h->o.seed, nb); });
+#else
+    hipLaunchKernelGGL(k_init, dim3(nb), dim3(256), 0, h->stream, h->M, h->S, (unsigned long long)h->o.seed);
+    int rc = launch_check();
+    if (rc) return rc;
+#endif
+    return reset_optimizer(h);
+}
+
+extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega) {
+    if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    int rc;
+    if ((rc = h2d(h->S.mu, mu, (size_t)h->M.D * 8, h->stream))) return rc;
+    if ((rc = h2d(h->S.om, omega, (size_t)h->M.D * 8, h->stream))) return rc;
+    return reset_optimizer(h);
+}
+
+extern "C" int bb_get_params(bb_handle* h, double* mu, double* omega) {
+    if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    int rc;
+    if ((rc = dsync(h->stream))) return rc;
+    if ((rc = d2h(mu, h->S.mu, (size_t)h->M.D * 8, h->stream))) return rc;
+    return d2h(omega, h->S.om, (size_t)h->M.D * 8, h->stream);
+}
+
+extern "C" int bb_get_posterior(bb_handle* h, double* mean, double* sigma) {
+    if (!h || !mean || !sigma) return bb_fail(BB_ERR_INVALID, "null argument");
+    int rc = bb_get_params(h, mean, sigma);
+    if (rc) return rc;
+    for (long long i = 0; i < h->M.D; ++i) {   // sigma = softplus(omega), O(D) once at the end
+        const double om = sigma[i];
+        sigma[i] = std::max(om, 0.0) + log1p(exp(-fabs(om)));
+    }
+    return BB_OK;
+}
+
+#ifndef BB_EMU
+static int build_graph(bb_handle* h, int steps) {
+    if (h->graph && h->graph_steps == steps) return 0;
+    if (h->graph) { (void)hipGraphExecDestroy(h->graph); h->graph = nullptr; }
+    hipGraph_t g = nullptr;
+    BB_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int i = 0; i < steps && !rc; ++i) rc = enqueue_step(h, i);   // parity of i == parity of the real step (even start)
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return bb_fail(BB_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { h->graph = nullptr; return bb_fail(BB_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    h->graph_steps = steps;
+    return 0;
+}
+#endif
+
+static int check_finite(bb_handle* h) {
+    if (h->o.elbo_every <= 0) return 0;
+    return 0;
+}
+
+extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
+    if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (h->sample != 0) return bb_fail(BB_ERR_INVALID, "a split-phase step is in flight");
+    int rc = 0;
+    int64_t done = 0;
+#ifndef BB_EMU
+    BB_HIP(hipEventRecord(h->ev0, h->stream));
+    // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
+    // pattern must repeat with the graph -> only when ELBO recording is off; no collectives inside.
+    int gs = h->o.steps_per_graph == 0 ? 50 : h->o.steps_per_graph;
+    const bool graph_ok = gs > 0 && h->o.world_size == 1 && h->o.elbo_every == 0;
+    if (graph_ok) {
+        gs &= ~1;
+        if (gs < 2) gs = 2;
+        if ((h->step & 1) && done < n_steps) { if ((rc = enqueue_step(h, h->step))) return rc; h->step++; done++; }
+        if (n_steps - done >= gs) {
+            if ((rc = build_graph(h, gs))) return rc;
+            while (n_steps - done >= gs) {
+                BB_HIP(hipGraphLaunch(h->graph, h->stream));
+                h->step += gs;
+                done += gs;
+            }
+        }
+    }
+#endif
+    for (; done < n_steps; ++done) {
+        if ((rc = enqueue_step(h, h->step))) return rc;
+        h->step++;
+    }
+#ifndef BB_EMU
+    BB_HIP(hipEventRecord(h->ev1, h->stream));
+    BB_HIP(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    BB_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_run_ms = ms;
+#endif
+    return check_finite(h);
+}
+
+extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
+    if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+#ifdef BB_EMU
+    return bb_run(h, n_steps);
+#else
+    if (h->use_reduce()) return bb_fail(BB_ERR_UNSUPPORTED, "bb_run_profiled covers the single-GPU two-kernel step only");
+    const int S = h->o.samples_per_step;
+    const size_t nl = (size_t)n_steps * S;
+    std::vector<hipEvent_t> ev(3 * nl);
+    for (auto& e : ev) BB_HIP(hipEventCreate(&e));
+    int rc = 0;
+    for (int64_t i = 0; i < n_steps && !rc; ++i) {
+        for (int s = 0; s < S && !rc; ++s) {
+            RunArgs A = make_args(h, h->step, s, S, true, elbo_wanted(h, h->step));
+            const size_t k = 3 * ((size_t)i * S + s);
+            BB_HIP(hipEventRecord(ev[k], h->stream));
+            rc = launch_sample(h, A);
+            BB_HIP(hipEventRecord(ev[k + 1], h->stream));
+            if (!rc) rc = launch_update(h, A);
+            BB_HIP(hipEventRecord(ev[k + 2], h->stream));
+        }
+        h->step++;
+    }
+    BB_HIP(hipStreamSynchronize(h->stream));
+    double ts = 0, tu = 0;
+    for (size_t k = 0; k < nl; ++k) {
+        float a = 0, b = 0;
+        BB_HIP(hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]));
+        BB_HIP(hipEventElapsedTime(&b, ev[3 * k + 1], ev[3 * k + 2]));
+        ts += a;
+        tu += b;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (nl) { h->avg_sample_ms = ts / nl; h->avg_update_ms = tu / nl; }
+    return rc;
+#endif
+}
+
+extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps, int32_t S,
+                            double* elbo, double* grad_mu, double* grad_omega) {
+    if (!h || !mu || !omega || S < 1) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (h->o.world_size > 1 && !eps) return bb_fail(BB_ERR_UNSUPPORTED, "bb_elbo_grad on a sharded handle needs explicit eps");
+    const size_t D = (size_t)h->M.D;
+    int rc;
+    if ((rc = d2d(h->bak_mu, h->S.mu, D * 8, h->stream))) return rc;
+    if ((rc = d2d(h->bak_om, h->S.om, D * 8, h->stream))) return rc;
+    if ((rc = h2d(h->S.mu, mu, D * 8, h->stream))) return rc;
+    if ((rc = h2d(h->S.om, omega, D * 8, h->stream))) return rc;
+    if (eps) {
+        if (h->eps_cap < (size_t)S * D) {
+            if (h->eps_buf) dfree(h->eps_buf);
+            h->eps_buf = nullptr;
+            void* p = nullptr;
+            if ((rc = dmalloc(&p, (size_t)S * D * 8))) return rc;
+            h->eps_buf = (double*)p;
+            h->eps_cap = (size_t)S * D;
+        }
+        if ((rc = h2d(h->eps_buf, eps, (size_t)S * D * 8, h->stream))) return rc;
+        h->S.eps_in = h->eps_buf;
+    }
+    double* es = nullptr;   // per-sample ELBO values
+    if (S > h->o.samples_per_step + 64) {
+        void* p = nullptr;
+        if ((rc = dmalloc(&p, (size_t)S * 8))) return rc;
+        es = (double*)p;
+    }
+    double* saved_es = h->S.elbo_sample;
+    if (es) h->S.elbo_sample = es;
+    for (int s = 0; s < S && !rc; ++s) {
+        RunArgs A = make_args(h, h->step, s, S, false, true);
+        rc = sample_half(h, A);
+        if (!rc) rc = allreduce(h, h->S.totals, (size_t)h->M.K);
+        if (!rc) rc = update_half(h, A);
+    }
+    std::vector<double> ev((size_t)S);
+    if (!rc) rc = d2h(ev.data(), h->S.elbo_sample, (size_t)S * 8, h->stream);
+    h->S.elbo_sample = saved_es;
+    if (es) dfree(es);
+    h->S.eps_in = nullptr;
+    if (!rc && grad_mu) rc = d2h(grad_mu, h->S.gacc_mu, D * 8, h->stream);
+    if (!rc && grad_omega) rc = d2h(grad_omega, h->S.gacc_om, D * 8, h->stream);
+    int rc2 = d2d(h->S.mu, h->bak_mu, D * 8, h->stream);
+    int rc3 = d2d(h->S.om, h->bak_om, D * 8, h->stream);
+    int rc4 = dsync(h->stream);
+    if (rc) return rc;
+    if (rc2 || rc3 || rc4) return rc2 ? rc2 : (rc3 ? rc3 : rc4);
+    if (elbo) {
+        double v = 0;
+        for (int s = 0; s < S; ++s) v += ev[(size_t)s];
+        *elbo = v / S;
+    }
+    return BB_OK;
+}
+
+extern "C" int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out) {
+    if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (h->o.elbo_every <= 0) return bb_fail(BB_ERR_INVALID, "ELBO recording is off (elbo_every = 0)");
+    std::vector<double> ring(BB_ELBO_RING);
+    int rc = dsync(h->stream);
+    if (rc) return rc;
+    if ((rc = d2h(ring.data(), h->S.elbo_ring, ring.size() * 8, h->stream))) return rc;
+    const int64_t ev = h->o.elbo_every;
+    const int64_t newest = h->step > 0 ? (h->step - 1) / ev : -1;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t st = first_step + k * ev;
+        const int64_t idx = st / ev;
+        const bool have = st % ev == 0 && st >= 0 && st < h->step && idx > newest - BB_ELBO_RING;
+        out[k] = have ? ring[(size_t)(idx % BB_ELBO_RING)] : NAN;
+    }
+    return BB_OK;
+}
+
+extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, int64_t hi, double* out) {
+    if (!h || !out || lo < 0 || hi < lo) return bb_fail(BB_ERR_INVALID, "bad argument");
+    const size_t n = (size_t)(hi - lo);
+    if (n == 0) return BB_OK;
+    int rc;
+    if (h->dbg_cap < n) {
+        if (h->dbg_buf) dfree(h->dbg_buf);
+        h->dbg_buf = nullptr;
+        void* p = nullptr;
+        if ((rc = dmalloc(&p, n * 8))) return rc;
+        h->dbg_buf = (double*)p;
+        h->dbg_cap = n;
+    }
+    const int nb = (int)std::min<size_t>((n / 2 + 256) / 256, 1024);
+#ifdef BB_EMU
+    emu_launch(nb, 256, 0, [&](BBCtx& cx) { bb_block_normals(cx, h->o.seed, (unsigned)step, stream, lo, hi, h->dbg_buf, nb); });
+#else
+    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(256), 0, h->stream, (unsigned long long)h->o.seed, (unsigned)step, stream,
+                       (long long)lo, (long long)hi, h->dbg_buf);
+    if ((rc = launch_check())) return rc;
+#endif
+    return d2h(out, h->dbg_buf, n * 8, h->stream);
+}
+
+extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
+    if (!h || !s) return bb_fail(BB_ERR_INVALID, "null argument");
+    memset(s, 0, sizeof *s);
+    s->n_latents = h->M.D;
+    s->n_moments = h->M.K;
+    s->steps_done = h->step;
+    s->shard_lo = h->b_lo;
+    s->shard_hi = h->b_hi;
+    s->bytes_sample = h->bytes_sample;
+    s->bytes_update = h->bytes_update;
+    s->bytes_per_step = h->bytes_update;   // theta read once when the two sweeps are fused (96 D + 4 TBR)
+    s->last_run_ms = h->last_run_ms;
+    s->avg_sample_ms = h->avg_sample_ms;
+    s->avg_update_ms = h->avg_update_ms;
+    s->n_blocks = h->nblk;
+    s->block_threads = h->nthr;
+    s->lds_bytes = (int32_t)(h->lds_doubles * 8);
+    return BB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sharded execution
+// ------------------------------------------------------------------------------------------------
+extern "C" int bb_comm_make_id(void* id_out) {
+    if (!id_out) return bb_fail(BB_ERR_INVALID, "null argument");
+#ifdef BB_EMU
+    return bb_fail(BB_ERR_COMM, "no RCCL in the emulation build");
+#else
+    int rc = rccl_load();
+    if (rc) return rc;
+    bb_ncclUniqueId id;
+    rc = g_rccl.GetUniqueId(&id);
+    if (rc) return bb_fail(BB_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    memcpy(id_out, &id, sizeof id);
+    return BB_OK;
+#endif
+}
+
+extern "C" int bb_comm_init(bb_handle* h, const void* id_in) {
+    if (!h || !id_in) return bb_fail(BB_ERR_INVALID, "null argument");
+#ifdef BB_EMU
+    return bb_fail(BB_ERR_COMM, "no RCCL in the emulation build");
+#else
+    int rc = rccl_load();
+    if (rc) return rc;
+    BB_HIP(hipSetDevice(h->o.device));
+    bb_ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    rc = g_rccl.CommInitRank(&h->comm, h->o.world_size, id, h->o.rank);
+    if (rc) { h->comm = nullptr; return bb_fail(BB_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); }
+    return BB_OK;
+#endif
+}
+
+extern "C" int bb_step_moments(bb_handle* h, double* partial) {
+    if (!h || !partial) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (h->M.kind == BB_MODEL_GENOTYPE && h->o.world_size > 1)
+        return bb_fail(BB_ERR_UNSUPPORTED, "split-phase stepping of the sharded genotype model needs a second exchange; use bb_comm_init + bb_run");
+    const int S = h->o.samples_per_step;
+    RunArgs A = make_args(h, h->step, h->sample, S, true, elbo_wanted(h, h->step));
+    A.red = h->S.totals;   // the caller-reduced totals come back through bb_step_apply
+    A.nred = 1;
+    int rc;
+    if (h->M.kind == BB_MODEL_GENOTYPE && (rc = launch_geno(h, A, 0, 1, 0))) return rc;
+    if ((rc = launch_sample(h, A))) return rc;
+    if ((rc = launch_reduce(h))) return rc;
+    return d2h(partial, h->S.totals, (size_t)h->M.K * 8, h->stream);
+}
+
+extern "C" int bb_step_apply(bb_handle* h, const double* total) {
+    if (!h || !total) return bb_fail(BB_ERR_INVALID, "null argument");
+    const int S = h->o.samples_per_step;
+    RunArgs A = make_args(h, h->step, h->sample, S, true, elbo_wanted(h, h->step));
+    A.red = h->S.totals;
+    A.nred = 1;
+    int rc;
+    if ((rc = h2d(h->S.totals, total, (size_t)h->M.K * 8, h->stream))) return rc;
+    if ((rc = update_half(h, A))) return rc;
+    if (++h->sample == S) { h->sample = 0; h->step++; }
+    return dsync(h->stream);
+}

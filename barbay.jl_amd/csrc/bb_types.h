@@ -1,0 +1,85 @@
+// bb_types.h -- POD descriptors shared by the host engine and the device block programs.
+#pragma once
+#include <stdint.h>
+
+#define BB_MAX_REP 16
+
+// `~` blocks of the model family, in a fixed kind numbering (not source order).
+enum BBBlockKind {
+    BK_SPOP = 0,   // s_pop        population mean fitness per time step (global)
+    BK_LSPOP = 1,  // logsigma_pop (global)
+    BK_S = 2,      // s_bc (fitness, multienv) or theta (genotype: per genotype; replicate: per mutant)
+    BK_TT = 3,     // theta_tilde
+    BK_LT = 4,     // logtau
+    BK_LS = 5,     // logsigma_bc
+    BK_L = 6,      // loglambda
+    BK_COUNT = 7
+};
+
+// moment rows per (replicate, time step): S_t, then for t < T-1: M0 M1 M2 N1 N2
+#define BB_NQ 6
+
+struct DevPrior {
+    double mean, inv_var;          // Vector form
+    const double* mean_e;          // Matrix form (device), indexed by i - blk_lo; nullptr = Vector form
+    const double* inv_var_e;
+};
+
+struct DevModel {
+    int kind, R, E, G;
+    long long nn, nb, B, D;
+    int T[BB_MAX_REP];
+    unsigned Tmagic[BB_MAX_REP];      // floor(2^32 / T) + 1: n / T == umulhi(n, magic) for n < 2^16
+    unsigned Tmagic1[BB_MAX_REP];     // same for T - 1
+    long long off_l[BB_MAX_REP];      // flat index of replicate r's loglambda slab
+    int off_t[BB_MAX_REP];            // first time step of replicate r inside s_pop / logsigma_pop
+    long long cnt_off[BB_MAX_REP];    // offset of replicate r in counts
+    int kq[BB_MAX_REP];               // first moment row of replicate r
+    int tcum[BB_MAX_REP];             // sum_{r' < r} T_r'
+    int Ttot, nt1, K;
+    long long blk_lo[BK_COUNT], blk_hi[BK_COUNT];
+    DevPrior pri[BK_COUNT];
+    const int* env_idx;               // device [T]
+    const int* geno_idx;              // device [nb]
+    const int* geno_ptr;              // device [G+1]   CSR over genotypes
+    const int* geno_mem;              // device [nb]    mutant indices grouped by genotype
+    const unsigned* counts;           // device, uint32, same indexing as loglambda minus blk_lo
+};
+
+struct DevState {
+    double *mu, *om;                  // [D] variational parameters theta = [mu; omega]
+    double *eps, *sp, *sig;           // [D] per-sample scratch: draw, softplus(omega), sigmoid(omega)
+    double *acc_mu, *acc_om;          // [D] optimiser accumulators
+    double *hist;                     // [W][2][D] TruncatedADAGrad window of squared gradients
+    double *gacc_mu, *gacc_om;        // [D] S > 1 accumulation / gradient export
+    double *partials;                 // [K][nblk]
+    double *totals;                   // [K]
+    double *zg;                       // [2 nt1] sampled global latents
+    double *ztheta;                   // [G] sampled genotype fitness (genotype model)
+    double *ds;                       // [nb] dlogp/ds_eff per mutant (genotype model)
+    double *gsum;                     // [G] per-genotype sums of ds
+    double *geno_el;                  // [geno blocks] ELBO partials of the theta block
+    double *elbo_ring;                // [BB_ELBO_RING]
+    double *elbo_sample;              // [S]
+    unsigned long long *ctr;          // [2] device-side step counter (ping-pong)
+    const double *eps_in;             // [S][D] caller-supplied draws (test hook) or nullptr
+};
+
+#define BB_ELBO_RING 4096
+
+struct RunArgs {
+    long long b_lo, b_hi;             // barcode shard [b_lo, b_hi)
+    int nblk;                         // blocks of the barcode grid
+    int par;                          // which ctr[] word holds the current step
+    int sample, S;
+    int first_sample, last_sample;    // of this step
+    int apply;                        // 1 = optimiser update, 0 = export gradient to gacc_*
+    int with_elbo;
+    int count_globals;                // this rank adds the replicated blocks' ELBO terms
+    int opt, W, resum_every, elbo_every;
+    double eta, tau, pre, post;
+    unsigned long long seed;
+    const double* red;                // moment rows to finalise: [K][nred]
+    int nred;
+    double elbo_const;
+};

@@ -1,0 +1,189 @@
+/* barbay_hip.h -- C ABI of the MI355X-native ADVI engine behind BarBay.vi.advi().
+ *
+ * Drop-in boundary: the one line this library replaces in the reference is
+ *     q = Turing.vi(bayes_model, advi; optimizer=opt)          (src/vi.jl:201)
+ * Everything before it (src/vi.jl:103-198) produces the inputs described by
+ * bb_model_desc / bb_advi_opts; everything after it (src/vi.jl:203-234,
+ * src/utils.jl:1042-1078, 1409-1462) reads only q.dist.m, q.dist.σ and
+ * q.transform.ranges_out, which bb_get_posterior / bb_get_layout return.
+ *
+ * Conventions
+ *  - plain C, no C++ exceptions cross the boundary; every int-returning entry
+ *    point returns BB_OK (0) or a negative BB_ERR_* code, with a thread-local
+ *    message available from bb_last_error().
+ *  - the caller owns every host array it passes; the library copies what it
+ *    needs during the call and never retains a host pointer.
+ *  - the flat latent vector is the concatenation of the model's `~` blocks in
+ *    source order with Julia column-major indexing.
+ *  - one handle = one host thread at a time = one GPU.
+ */
+#ifndef BARBAY_HIP_H
+#define BARBAY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BB_OK 0
+#define BB_ERR_INVALID (-1)   /* bad argument / inconsistent description     */
+#define BB_ERR_DEVICE (-2)    /* HIP runtime error                           */
+#define BB_ERR_COMM (-3)      /* RCCL error / communicator not initialised   */
+#define BB_ERR_UNSUPPORTED (-4)
+#define BB_ERR_NUMERIC (-5)   /* non-finite ELBO partials detected           */
+
+/* model kinds: BarBay.model.* entries on the hot path */
+#define BB_MODEL_FITNESS 0    /* fitness_normal            src/model_fitness_normal.jl:120-272 */
+#define BB_MODEL_MULTIENV 1   /* multienv_fitness_normal   src/model_multienv_fitness_normal.jl:133-303 */
+#define BB_MODEL_GENOTYPE 2   /* genotype_fitness_normal   src/model_fitness_normal_hierarchical_genotypes.jl:151-330 */
+#define BB_MODEL_REPLICATE 3  /* replicate_fitness_normal  src/model_fitness_normal_hierarchical_replicates.jl:145-332 (3-D)
+                                 and :407-638 (ragged); equal n_time[] == the 3-D method */
+
+/* optimisers selectable at src/vi.jl:99 (AdvancedVI 0.2) */
+#define BB_OPT_TRUNCATED_ADAGRAD 0
+#define BB_OPT_DECAYED_ADAGRAD 1
+
+/* A prior argument of a model (`VecOrMat{Float64}`, model_fitness_normal.jl:125-129):
+ * n == 1  : Vector form [mean, std] shared by the block;
+ * n == len: Matrix form, mean[i], std[i] per element of the block. */
+typedef struct bb_prior {
+    const double* mean;
+    const double* std;
+    int64_t n;
+} bb_prior;
+
+/* What `model(R, n_t, n_neutral, n_bc; kwargs...)` receives (src/vi.jl:172-178),
+ * in the layout src/utils.jl:48-61 (DataArrays) hands over. */
+typedef struct bb_model_desc {
+    int32_t kind;            /* BB_MODEL_*                                                */
+    int32_t n_rep;           /* replicates (1 unless BB_MODEL_REPLICATE)                  */
+    int64_t n_neutral;       /* neutral barcodes: columns 0..n_neutral-1 (utils.jl:431)   */
+    int64_t n_bc;            /* mutant barcodes                                           */
+    const int32_t* n_time;   /* [n_rep] time points per replicate                         */
+    const int64_t* counts;   /* replicate-major; each T_r x B column-major (t fastest)    */
+    const int64_t* totals;   /* replicate-major; [T_r] = row sums of counts               */
+    int32_t n_env;           /* BB_MODEL_MULTIENV: number of distinct environments        */
+    const int32_t* env_idx;  /* [T] 0-based env of each time point (indexin(envs, unique))*/
+    int32_t n_geno;          /* BB_MODEL_GENOTYPE: number of distinct genotypes           */
+    const int32_t* geno_idx; /* [n_bc] 0-based genotype of each mutant                    */
+    bb_prior s_pop_prior;        /* default [0,2] */
+    bb_prior logsigma_pop_prior; /* default [0,1] */
+    bb_prior s_bc_prior;         /* default [0,2]; theta prior for the hierarchical models */
+    bb_prior logsigma_bc_prior;  /* default [0,1] */
+    bb_prior loglambda_prior;    /* default [3,3] */
+    bb_prior logtau_prior;       /* default [-2,1]; Vector form only (as in the reference) */
+} bb_model_desc;
+
+/* Turing.ADVI(samples_per_step, max_iters) + optimiser + engine options. */
+typedef struct bb_advi_opts {
+    int32_t samples_per_step; /* S >= 1                                                  */
+    int32_t optimizer;        /* BB_OPT_*                                                */
+    double eta;               /* both optimisers, default 0.1                            */
+    double tau;               /* TruncatedADAGrad, default 40                            */
+    int32_t window;           /* TruncatedADAGrad n, default 100                         */
+    int32_t resum_every;      /* TruncatedADAGrad: 1 = re-add the whole window every step
+                                 (same arithmetic as the reference's sum(g2)); k > 1 =
+                                 running sum, exact re-add every k steps; 0 = window     */
+    double pre;               /* DecayedADAGrad, default 1.0                             */
+    double post;              /* DecayedADAGrad, default 0.9                             */
+    uint64_t seed;            /* Philox key (DESIGN.md "RNG stream")                     */
+    int32_t device;           /* HIP device ordinal                                      */
+    int32_t rank;             /* barcode shard owned by this handle                      */
+    int32_t world_size;       /* number of shards (1 = whole problem)                    */
+    int32_t steps_per_graph;  /* steps captured per hipGraph (0 = default, <0 = eager)   */
+    int32_t elbo_every;       /* evaluate the ELBO every k-th step (0 = never)           */
+} bb_advi_opts;
+
+typedef struct bb_handle bb_handle;
+
+typedef struct bb_block_range {
+    char name[24];  /* s_pop, logsigma_pop, s_bc, logsigma_bc, theta, theta_tilde, logtau, loglambda */
+    int64_t lo;     /* 0-based, half-open: q.transform.ranges_out[i] == lo+1 : hi                     */
+    int64_t hi;
+} bb_block_range;
+
+typedef struct bb_stats {
+    int64_t n_latents;         /* D                                                      */
+    int64_t n_moments;         /* K doubles all-reduced per MC sample                    */
+    int64_t steps_done;
+    int64_t shard_lo, shard_hi;/* barcode range owned by this handle                     */
+    int64_t bytes_per_step;    /* algorithmic HBM bytes per step on this shard           */
+    int64_t bytes_sample, bytes_update; /* its split over the two kernels                */
+    double last_run_ms;        /* HIP-event time of the last bb_run                      */
+    double avg_sample_ms;      /* per-launch averages from the last bb_run_profiled      */
+    double avg_update_ms;
+    int32_t n_blocks, block_threads, lds_bytes;
+} bb_stats;
+
+const char* bb_version(void);
+const char* bb_last_error(void);
+
+void bb_default_opts(bb_advi_opts* opts);
+
+/* Build device state for one model instance.  Validates the description
+ * (shapes, totals == row sums, index ranges) and copies everything it needs. */
+int bb_create(const bb_model_desc* model, const bb_advi_opts* opts, bb_handle** out);
+void bb_destroy(bb_handle* h);
+
+int64_t bb_num_latents(const bb_handle* h);
+/* blocks[0..*n_blocks): one range per `~` block in source order (<= 8). */
+int bb_get_layout(const bb_handle* h, bb_block_range* blocks, int32_t* n_blocks);
+
+/* Turing.meanfield initialisation (mu0 = randn(D), sigma0 = softplus.(randn(D)))
+ * drawn from the engine's own init streams; resets optimiser state and step. */
+int bb_init_meanfield(bb_handle* h);
+/* Explicit variational parameters theta = [mu; omega], sigma = softplus(omega);
+ * resets optimiser state and step. */
+int bb_set_params(bb_handle* h, const double* mu, const double* omega);
+int bb_get_params(bb_handle* h, double* mu, double* omega);
+
+/* AdvancedVI.optimize!: n_steps iterations of
+ *   grad(-ELBO) with S reparameterised samples -> optimiser -> theta -= delta. */
+int bb_run(bb_handle* h, int64_t n_steps);
+/* Same arithmetic, launched eagerly with a HIP event pair around every kernel
+ * so that per-kernel durations can be reported (bb_stats.avg_*_ms). */
+int bb_run_profiled(bb_handle* h, int64_t n_steps);
+
+/* q.dist.m and q.dist.sigma (= softplus(omega)) -- what utils.advi_to_df reads
+ * (src/utils.jl:1060).  With world_size > 1 only this handle's shard (and the
+ * replicated global blocks) is meaningful; see bb_get_stats().shard_*. */
+int bb_get_posterior(bb_handle* h, double* mean, double* sigma);
+
+/* Deterministic test hook: ELBO estimate and its gradient at theta = [mu; omega]
+ * with caller-supplied standard-normal draws eps (S x D row-major; NULL = the
+ * Philox stream of the current step).  Does not touch optimiser state. */
+int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps,
+                 int32_t n_samples, double* elbo, double* grad_mu, double* grad_omega);
+
+/* ELBO estimates recorded by bb_run (elbo_every > 0): values of steps
+ * first_step, first_step + elbo_every, ... ; NaN where not recorded/kept. */
+int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out);
+
+/* The engine's normal stream for (step, stream) over latents [lo, hi), for checks. */
+int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, int64_t hi, double* out);
+
+int bb_get_stats(bb_handle* h, bb_stats* out);
+
+/* ---- sharded execution -------------------------------------------------------------
+ * Barcodes shard over world_size handles (one process per GPU).  Per MC sample the
+ * only exchange is the sum of K = bb_stats.n_moments doubles.
+ *
+ * (1) in-library: RCCL over xGMI.  Rank 0 makes an id, the caller broadcasts it
+ *     (e.g. torch.distributed), every rank calls bb_comm_init; bb_run then issues one
+ *     ncclAllReduce per sample on the engine's stream. */
+#define BB_COMM_ID_BYTES 128
+int bb_comm_make_id(void* id_out /* BB_COMM_ID_BYTES */);
+int bb_comm_init(bb_handle* h, const void* id /* BB_COMM_ID_BYTES */);
+/* (2) split-phase, caller-supplied reducer (MPI, gloo, Julia Distributed ...):
+ *     bb_step_moments runs the sampling sweep of the next MC sample and returns this
+ *     shard's K partial moments; the caller sums them over shards and passes the
+ *     totals to bb_step_apply, which finishes the sample (and the step after the
+ *     S-th sample). */
+int bb_step_moments(bb_handle* h, double* partial /* K */);
+int bb_step_apply(bb_handle* h, const double* total /* K */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BARBAY_HIP_H */
