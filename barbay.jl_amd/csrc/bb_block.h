@@ -529,7 +529,7 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
         const unsigned magic1 = M.Tmagic1[r];
         BB_PASS(cx, tid) {
             for (int j = tid; j < t.nbt * T1; j += cx.nthr) {
-                const int bl = (int)bb_umulhi((unsigned)j, magic1), tt = j - bl * T1;
+                const int bl = T1 == 1 ? j : (int)bb_umulhi((unsigned)j, magic1), tt = j - bl * T1;
                 double a = zl[bl * T + tt + 1] - zl[bl * T + tt];
                 if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof(M, r, tt)];
                 res[j] = a - lds[L.cc + tc + tt];

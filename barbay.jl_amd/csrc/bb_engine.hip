@@ -323,7 +323,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         if (T < 2 || T > 255) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "n_time[%d] = %d outside 2..255", r, T); }
         M.T[r] = T;
         M.Tmagic[r] = (unsigned)(0x100000000ull / (unsigned)T) + 1u;
-        M.Tmagic1[r] = (unsigned)(0x100000000ull / (unsigned)(T - 1)) + 1u;
+        M.Tmagic1[r] = T > 2 ? (unsigned)(0x100000000ull / (unsigned)(T - 1)) + 1u : 0u;   // T - 1 == 1: no division
         M.off_t[r] = M.nt1;
         M.cnt_off[r] = cnt;
         M.kq[r] = M.K;

@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""ELBO-gradient steps/s of the MI355X-native ADVI engine on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one ADVI iteration (S = 1 reparameterised sample of the ELBO gradient + one
+TruncatedADAGrad update of all 2D variational parameters) of `fitness_normal` on the synthetic
+50 000 barcodes x 8 time points workload (config C2, seed 42), inputs resident in HBM.  With N > 1
+the barcodes shard over the ranks (one process per GPU) and every step carries one RCCL all-reduce
+of the K moment rows, so the job is strong-scaled: `value` is the step rate of the whole job.
+
+Prints ONE JSON line on rank 0 with the driver's contract plus `roofline` (dominant kernel, HIP
+events on the engine's stream) and `cpu_baseline` (the oracle's C port on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(wl, seconds_budget: float = 20.0):
+    """Time the oracle's fused C port (oracle/c/bb_port.c) on the same workload, same options."""
+    from oracle import port
+    ncores = os.cpu_count() or 1
+    return port.time_workload(wl, ncores, seconds_budget)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--barcodes", type=int, default=50_000)
+    ap.add_argument("--timepoints", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=200, help="eagerly launched steps timed per kernel for `roofline`")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import barbay_jl_amd as bb
+    from barbay_jl_amd import synth
+
+    wl = synth.fitness_normal(args.barcodes, args.timepoints, seed=42)
+    eng = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, device=local_rank, rank=rank, world_size=world)
+    if world > 1:
+        ids = [eng.make_comm_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    eng.run(args.steps)          # returns after the engine's stream has drained
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+    mu, sigma = eng.posterior()
+    finite = bool(np.isfinite(mu).all() and np.isfinite(sigma).all())
+
+    roofline = None
+    if world == 1:
+        eng.run_profiled(args.profile_steps)
+        sp = eng.stats()
+        upd_s = sp["avg_update_ms"] * 1e-3
+        ach = sp["bytes_update"] / upd_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_update", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(sp["bytes_update"]),
+                    "avg_launch_us": round(sp["avg_update_ms"] * 1e3, 2),
+                    "other_kernels": {"k_sample": {"avg_launch_us": round(sp["avg_sample_ms"] * 1e3, 2),
+                                                   "algorithmic_bytes_per_launch": int(sp["bytes_sample"])}}}
+        tr = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(tr):
+            try:
+                roofline["traffic"] = json.load(open(tr)).get("k_update_bytes_per_launch")
+            except Exception:
+                pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl)
+
+    if rank == 0:
+        out = {
+            "metric": "ELBO-grad steps/sec, 50k barcodes x 8 timepoints",
+            "value": round(args.steps / dt, 2),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "model": "fitness_normal", "barcodes": wl.B, "timepoints": args.timepoints,
+                       "n_latents": int(st["n_latents"]), "samples_per_step": 1,
+                       "optimizer": "TruncatedADAGrad(0.1, 40, 100)", "sharding": f"barcodes/{world}",
+                       "collective": "none" if world == 1 else f"1 ncclAllReduce of {int(st['n_moments'])} f64 per step"},
+            "posterior_finite": finite,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

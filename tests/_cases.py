@@ -1,0 +1,173 @@
+"""Parity cases shared by the emulation tests (CPU, `-m "not gpu"`) and the GPU tests (`-m gpu`).
+Each takes the loaded C-ABI library (`lib`) and compares the engine with the oracle."""
+import os
+
+import numpy as np
+
+from conftest import make_engine
+from oracle import advi, fixtures, literal, rng
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# deterministic tolerances: fp64, |dELBO|/|ELBO| <= 1e-12, max|dgrad| <= 1e-9 max|grad|
+ELBO_RTOL = 1e-12
+GRAD_RTOL = 1e-9
+
+SYNTH = {
+    "fitness_multi_tile": ("fitness", dict(B=700, T=5, n_neutral=37)),
+    "fitness_neutral_heavy": ("fitness", dict(B=513, T=8, n_neutral=300)),
+    "fitness_T2": ("fitness", dict(B=130, T=2, n_neutral=3)),
+    "multienv": ("multienv", dict(B=600, T=7, n_env=3, n_neutral=11)),
+    "genotype": ("genotype", dict(B=800, T=6, n_geno=17, n_neutral=256)),
+    "replicate_ragged": ("replicate", dict(B=530, T=[5, 7, 4], n_rep=3, n_neutral=20)),
+    "replicate_3d": ("replicate", dict(B=300, T=6, n_rep=2, n_neutral=1)),
+}
+
+
+def synth(name, seed=5, **pri):
+    kind, kw = SYNTH[name]
+    return fixtures.synthetic(kind, seed=seed, **kw, **pri)
+
+
+def check_grad(e, sp, mu, om, eps):
+    el, gm, go = literal.elbo_and_grad(mu, om, eps, sp)
+    el2, gm2, go2 = e.elbo_grad(mu, om, eps)
+    assert abs(el - el2) <= 50 * ELBO_RTOL * abs(el), (el, el2)   # lgamma/sum order: a few ulps of 1e9-sized sums
+    assert np.abs(gm - gm2).max() <= GRAD_RTOL * np.abs(gm).max()
+    assert np.abs(go - go2).max() <= GRAD_RTOL * np.abs(go).max()
+
+
+def case_golden(lib, name):
+    gold = np.load(os.path.join(GOLD, f"golden_{name}.npz"))
+    sp = fixtures.load(name)
+    with make_engine(sp, lib) as e:
+        assert e.D == int(gold["D"])
+        lay = e.layout()
+        assert [(n, lo, hi) for n, (lo, hi) in sp.offsets().items()] == lay
+        el, gm, go = e.elbo_grad(gold["mu"], gold["omega"], gold["eps"])
+        assert abs(el - float(gold["elbo"])) <= 50 * ELBO_RTOL * abs(el)
+        assert np.abs(gm - gold["grad_mu"]).max() <= GRAD_RTOL * np.abs(gold["grad_mu"]).max()
+        assert np.abs(go - gold["grad_omega"]).max() <= GRAD_RTOL * np.abs(gold["grad_omega"]).max()
+        # log-joint and its gradient: eps = 0 => z = mu, dELBO/dmu = grad logjoint, ELBO = logjoint + H
+        z = gold["z"]
+        om = np.full(sp.D, -1.0)
+        H = 0.5 * sp.D * (1 + np.log(2 * np.pi)) + np.log(advi.softplus(om)).sum()
+        el0, g0, _ = e.elbo_grad(z, om, np.zeros((1, sp.D)))
+        assert abs((el0 - H) - float(gold["logjoint"])) <= 50 * ELBO_RTOL * abs(el0)
+        assert np.abs(g0 - gold["grad_z"]).max() <= GRAD_RTOL * np.abs(gold["grad_z"]).max()
+
+
+def case_synth_grad(lib, name):
+    sp = synth(name)
+    with make_engine(sp, lib, seed=9) as e:
+        mu0, om0 = advi.meanfield_init(9, sp.D)
+        m, o = e.get_params()
+        assert np.abs(m - mu0).max() < 1e-13 and np.abs(o - om0).max() < 1e-13
+        mu, om = mu0 * 0.2 + 3, om0 * 0.5 - 2
+        eps = np.stack([rng.normals(9, 4, s, sp.D) for s in range(3)])
+        check_grad(e, sp, mu, om, eps)
+        # engine's own Philox stream (eps = NULL) at its current step (0), two samples
+        e.set_params(mu, om)
+        el3, gm3, go3 = e.elbo_grad(mu, om, None, 2)
+        eps0 = np.stack([rng.normals(9, 0, s, sp.D) for s in range(2)])
+        el4, gm4, go4 = literal.elbo_and_grad(mu, om, eps0, sp)
+        assert abs(el3 - el4) <= 1e-10 * abs(el4)
+        assert np.abs(gm3 - gm4).max() <= 1e-8 * np.abs(gm4).max()
+
+
+def case_normals(lib):
+    sp = fixtures.load("data001_single")
+    with make_engine(sp, lib, seed=0xDEADBEEF12345) as e:
+        for (step, stream, lo, hi) in [(0, 0, 0, 103), (7, 1, 3, 50), (123456, rng.STREAM_INIT_MU, 10, 11), (2 ** 32 - 1, 5, 0, 2)]:
+            got = e.normals(step, stream, lo, hi)
+            want = rng.normals(0xDEADBEEF12345, step, stream, 103, lo, hi)
+            assert np.abs(got - want).max() < 1e-13
+        big = e.normals(3, 0, 0, 400000)
+        assert abs(big.mean()) < 0.01 and abs(big.std() - 1) < 0.01
+
+
+def _trajectory(lib, sp, nsteps, S, optname, seed=11, use_priors=False, **ekw):
+    e = make_engine(sp, lib, use_priors=use_priors, seed=seed, samples_per_step=S, optimizer=optname, **ekw)
+    mu0, om0 = e.get_params()
+    e.run(nsteps)
+    mu, om = e.get_params()
+    opt = advi.TruncatedADAGrad(n=ekw.get("window", 100)) if optname == "TruncatedADAGrad" else advi.DecayedADAGrad()
+    f = lambda m, o, eps: literal.elbo_and_grad(m, o, eps, sp)
+    m2, o2, tr = advi.run_advi(sp, f, mu0, om0, nsteps, S, opt, seed)
+    return e, np.abs(mu - m2).max(), np.abs(om - o2).max(), tr
+
+
+def case_trajectory_exact(lib, name, optname, S, tol=1e-10):
+    """resum_every=1: the window is re-added every step, the reference's own arithmetic."""
+    sp = synth(name, seed=2)
+    e, a, b, _ = _trajectory(lib, sp, 12, S, optname, window=5, resum_every=1)
+    e.close()
+    assert a < tol and b < tol, (a, b)
+
+
+def case_trajectory_running(lib, name, graph=0):
+    """default running-window sum (exact re-add once per window) + ELBO trace."""
+    sp = synth(name, seed=2)
+    e, a, b, tr = _trajectory(lib, sp, 23, 1, "TruncatedADAGrad", window=5, elbo_every=1, steps_per_graph=graph)
+    got = e.elbo_trace(0, 23)
+    e.close()
+    assert a < 1e-6 and b < 1e-6, (a, b)
+    assert np.abs(got - tr).max() <= 1e-6 * np.abs(tr).max()
+
+
+def case_matrix_priors(lib):
+    sp0 = synth("fitness_multi_tile", seed=3)
+    g = np.random.default_rng(0)
+    T = sp0.n_time[0]
+    pri = dict(loglambda_prior=(np.log(sp0.counts[0].T.reshape(-1) + 1.0), g.uniform(0.5, 3, sp0.B * T)),
+               s_pop_prior=(g.normal(0, 1, T - 1), g.uniform(0.05, 1, T - 1)),
+               s_bc_prior=(g.normal(0, 1, sp0.n_bc), g.uniform(0.5, 2, sp0.n_bc)),
+               logsigma_bc_prior=(0.5, 0.7),
+               logsigma_pop_prior=(g.normal(0, 1, T - 1), g.uniform(0.5, 1, T - 1)))
+    sp = synth("fitness_multi_tile", seed=3, **pri)
+    e, a, b, tr = _trajectory(lib, sp, 8, 1, "TruncatedADAGrad", use_priors=True, elbo_every=1, resum_every=1, window=4)
+    got = e.elbo_trace(0, 8)
+    e.close()
+    assert a < 1e-10 and b < 1e-10
+    assert np.abs(got - tr).max() <= 1e-11 * np.abs(tr).max()
+
+
+def case_sharded_split_phase(lib, name, W=3, S=2, nsteps=5):
+    """Barcode shards driven through bb_step_moments / bb_step_apply with a caller-side sum equal
+    the unsharded run (up to summation order)."""
+    sp = synth(name, seed=4)
+    with make_engine(sp, lib, seed=5, samples_per_step=S, window=4) as e1:
+        e1.run(nsteps)
+        m1, o1 = e1.get_params()
+        lay = {n: (lo, hi) for n, lo, hi in e1.layout()}
+    es = [make_engine(sp, lib, seed=5, samples_per_step=S, window=4, rank=r, world_size=W) for r in range(W)]
+    for _ in range(nsteps * S):
+        tot = sum(e.step_moments() for e in es)
+        for e in es:
+            e.step_apply(tot)
+    from barbay_jl_amd.sharding import gather_params
+    mu = gather_params([e.get_params()[0] for e in es], [e.stats() for e in es], sp.kind, lay, sp.n_neutral, sp.n_bc,
+                       sp.n_time, sp.n_rep, sp.n_env)
+    om = gather_params([e.get_params()[1] for e in es], [e.stats() for e in es], sp.kind, lay, sp.n_neutral, sp.n_bc,
+                       sp.n_time, sp.n_rep, sp.n_env)
+    for e in es:
+        e.close()
+    assert np.abs(mu - m1).max() < 1e-10 and np.abs(om - o1).max() < 1e-10
+
+
+def case_errors(lib):
+    import barbay_jl_amd as bb
+    import pytest
+    sp = fixtures.load("data001_single")
+    bad = [t.copy() for t in sp.totals]
+    bad[0][1] += 1
+    with pytest.raises(bb.BarBayHipError, match="totals"):
+        bb.Engine(sp.kind, sp.counts, sp.n_neutral, sp.n_bc, totals=bad, _lib=lib)
+    with pytest.raises(bb.BarBayHipError, match="Matrix form"):
+        bb.Engine(sp.kind, sp.counts, sp.n_neutral, sp.n_bc, priors={"s_bc_prior": (np.zeros(3), np.ones(3))}, _lib=lib)
+    with pytest.raises(bb.BarBayHipError, match="std"):
+        bb.Engine(sp.kind, sp.counts, sp.n_neutral, sp.n_bc, priors={"s_bc_prior": (0.0, -1.0)}, _lib=lib)
+    with pytest.raises(bb.BarBayHipError):
+        bb.Engine("multienv", sp.counts, sp.n_neutral, sp.n_bc, _lib=lib)   # env_idx missing
+    with pytest.raises(bb.BarBayHipError):
+        bb.Engine("fitness", sp.counts, sp.n_neutral, sp.n_bc, samples_per_step=0, _lib=lib)

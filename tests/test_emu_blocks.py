@@ -1,0 +1,45 @@
+"""CPU tests of the HIP block programs through their sequential host emulation (g++ -DBB_EMU build of
+barbay.jl_amd/csrc/bb_engine.hip).  Same cases as the GPU parity tests; covers the host logic of the
+engine (layout, validation, stepping, sharding) where no GPU exists."""
+import pytest
+
+import _cases as c
+
+
+@pytest.mark.parametrize("name", ["data001_single", "data002_hier-rep", "data003_multienv", "data004_multigen"])
+def test_golden(emu_lib, name):
+    c.case_golden(emu_lib, name)
+
+
+@pytest.mark.parametrize("name", list(c.SYNTH))
+def test_synth_grad(emu_lib, name):
+    c.case_synth_grad(emu_lib, name)
+
+
+def test_normals(emu_lib):
+    c.case_normals(emu_lib)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged"])
+@pytest.mark.parametrize("opt", ["TruncatedADAGrad", "DecayedADAGrad"])
+@pytest.mark.parametrize("S", [1, 2])
+def test_trajectory_exact(emu_lib, name, opt, S):
+    c.case_trajectory_exact(emu_lib, name, opt, S)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "replicate_3d"])
+def test_trajectory_running(emu_lib, name):
+    c.case_trajectory_running(emu_lib, name)
+
+
+def test_matrix_priors(emu_lib):
+    c.case_matrix_priors(emu_lib)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged"])
+def test_sharded_split_phase(emu_lib, name):
+    c.case_sharded_split_phase(emu_lib, name)
+
+
+def test_errors(emu_lib):
+    c.case_errors(emu_lib)
