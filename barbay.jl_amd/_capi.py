@@ -117,7 +117,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         import torch  # noqa: F401  (loads its libamdhip64.so.7 first so both share one HIP runtime)
     except Exception:
         pass
-    lib = _declare(C.CDLL(p, mode=C.RTLD_GLOBAL))
+    lib = _declare(C.CDLL(p))
     if path is None:
         _LIB = lib
     return lib
