@@ -92,11 +92,11 @@ static int dsync(bbStream s) { BB_HIP(hipStreamSynchronize(s)); return 0; }
 
 extern __shared__ __attribute__((aligned(16))) double bb_smem[];
 
-__global__ void __launch_bounds__(256) k_sample(DevModel M, DevState S, RunArgs A, int NB) {
+__global__ void __launch_bounds__(1024) k_sample(DevModel M, DevState S, RunArgs A, int NB) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_sample(cx, M, S, A, NB);
 }
-__global__ void __launch_bounds__(256) k_update(DevModel M, DevState S, RunArgs A, int NB) {
+__global__ void __launch_bounds__(1024) k_update(DevModel M, DevState S, RunArgs A, int NB) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_update(cx, M, S, A, NB);
 }
@@ -264,10 +264,6 @@ static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean,
     dp.mean_e = dm;
     dp.inv_var_e = di;
     return 0;
-}
-
-static size_t lds_bytes_for(const DevModel& M, int NB) {
-    return (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, NB).total * sizeof(double);
 }
 
 extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
@@ -442,26 +438,48 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     h->b_lo = M.B * opts->rank / opts->world_size;
     h->b_hi = M.B * (opts->rank + 1) / opts->world_size;
     {
+        // One workgroup per CU (XCD-agnostic: every tile is independent), sized so that the whole
+        // shard is resident at once: NB = ceil(barcodes / CUs) barcodes per tile, up to 1024 threads
+        // (16 waves per CU) working a tile's ~NB*(T+2) latents.  BB_TUNE_* env vars override for experiments.
         int maxT = 0;
         for (int r = 0; r < M.R; ++r) maxT = std::max(maxT, M.T[r]);
-        int NB = 256;
-        while (NB > 64 && lds_bytes_for(M, NB) > 64 * 1024) NB >>= 1;
-        while (NB < maxT) NB <<= 1;
-        if (lds_bytes_for(M, NB) > 160 * 1024 || (long long)NB * maxT >= 65536) {
+        int cus = 256;
+#ifndef BB_EMU
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, opts->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+#endif
+        const char* ev;
+        int bpc = (ev = getenv("BB_TUNE_BLOCKS_PER_CU")) ? atoi(ev) : 1;
+        if (bpc < 1) bpc = 1;
+        const long long nbar = std::max<long long>(h->b_hi - h->b_lo, 1);
+        long long target = (long long)cus * bpc;
+        int NB = (int)std::max<long long>((nbar + target - 1) / target, 32);
+        if ((ev = getenv("BB_TUNE_NB")) && atoi(ev) > 0) NB = atoi(ev);
+        const size_t lds_cap = (size_t)160 * 1024 / (size_t)bpc;
+        int nthr = 0;
+        for (;;) {
+            const long long lat = (long long)NB * (M.Ttot + 2);
+            nthr = lat >= 1536 ? 1024 : (lat >= 768 ? 512 : 256);
+            if ((ev = getenv("BB_TUNE_NTHR")) && atoi(ev) >= 64) nthr = atoi(ev) / 64 * 64;
+            while (nthr < maxT) nthr <<= 1;
+            const size_t need = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr).total * 8;
+            if ((need <= lds_cap && (long long)NB * maxT < 65536) || NB <= 8) break;
+            NB = (NB + 1) / 2;
+        }
+        const size_t need = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr).total * 8;
+        if (need > 160 * 1024 || nthr > 1024 || (long long)NB * maxT >= 65536) {
             bb_destroy(h);
-            return bb_fail(BB_ERR_UNSUPPORTED, "tile of %d barcodes needs %zu bytes of LDS (n_time too large for this build)", NB, lds_bytes_for(M, NB));
+            return bb_fail(BB_ERR_UNSUPPORTED, "a tile of %d barcodes needs %zu bytes of LDS / %d threads (n_time or n_rep too large for this build)", NB, need, nthr);
         }
         h->NB = NB;
-        h->nthr = NB;
-        h->lds_doubles = lds_bytes_for(M, NB) / 8;
-        h->nblk = (int)((h->b_hi - h->b_lo + NB - 1) / NB);
-        if (h->nblk < 1) h->nblk = 1;
+        h->nthr = nthr;
+        h->lds_doubles = need / 8;
+        h->nblk = (int)((nbar + NB - 1) / NB);
         h->ngeno_blk = M.G > 0 ? (int)std::min<long long>(((M.G + 1) / 2 + 255) / 256, 64) : 0;
 #ifndef BB_EMU
-        if (h->lds_doubles * 8 > 64 * 1024) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)k_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->lds_doubles * 8));
-            hipError_t e2 = hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->lds_doubles * 8));
-            if (e1 != hipSuccess || e2 != hipSuccess) { bb_destroy(h); return bb_fail(BB_ERR_DEVICE, "cannot raise dynamic LDS to %zu bytes", h->lds_doubles * 8); }
+        if (need > 64 * 1024) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)k_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipError_t e2 = hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (e1 != hipSuccess || e2 != hipSuccess) { bb_destroy(h); return bb_fail(BB_ERR_DEVICE, "cannot raise dynamic LDS to %zu bytes", need); }
         }
 #endif
     }

