@@ -22,7 +22,7 @@ BB_COMM_ID_BYTES = 128
 EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
     "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_run", "bb_run_profiled",
-    "bb_get_posterior", "bb_elbo_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_get_stats",
+    "bb_get_posterior", "bb_elbo_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats",
     "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply",
 ]
 
@@ -93,6 +93,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.bb_get_elbo_trace.argtypes = [vp, C.c_int64, C.c_int64, _dp]
     lib.bb_debug_normals.argtypes = [vp, C.c_int64, C.c_uint32, C.c_int64, C.c_int64, _dp]
     lib.bb_get_stats.argtypes = [vp, C.POINTER(bb_stats)]
+    lib.bb_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     lib.bb_comm_make_id.argtypes = [C.c_void_p]
     lib.bb_comm_init.argtypes = [vp, C.c_void_p]
     lib.bb_step_moments.argtypes = [vp, _dp]
@@ -272,6 +273,12 @@ class Engine:
     def normals(self, step: int, stream: int, lo: int, hi: int) -> np.ndarray:
         out = np.empty(hi - lo)
         self._check(self._lib.bb_debug_normals(self._h, step, stream, lo, hi, _ptr(out)))
+        return out
+
+    def stamps(self) -> np.ndarray:
+        nb = int(self.stats()["n_blocks"])
+        out = np.zeros((nb, 32), dtype=np.uint64)
+        self._check(self._lib.bb_debug_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), nb * 32))
         return out
 
     def stats(self) -> Dict[str, float]:

@@ -38,11 +38,22 @@ BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
 BB_DEV void bb_sincospi(double x, double* s, double* c) { sincospi(x, s, c); }
 #endif
 
+// In-kernel stamps (diagnostic build only, -DBB_STAMPS): s_memtime at pass boundaries of every block,
+// written to a buffer nothing else reads.  The shipped build compiles them out.
+#if defined(BB_STAMPS) && !defined(BB_EMU)
+#define BB_STAMP(cx, S, i) do { if (threadIdx.x == 0) (S).stamps[(long long)(cx).block * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BB_STAMP(cx, S, i) ((void)0)
+#endif
+
+#include "bb_math.h"
+
 #define BB_STREAM_INIT_MU 0xFFFFFFFFu
 #define BB_STREAM_INIT_OMEGA 0xFFFFFFFEu
 #define BB_LOG2PI 1.8378770664093454835606594728112
 
 struct alignas(16) bb_d2 { double x, y; };
+#define BB_MAX_SEG (4 + 4 * BB_MAX_REP)
 
 // ------------------------------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = (q_lo, q_hi, step, stream), key = seed; Box-Muller on two 53-bit
@@ -73,19 +84,14 @@ BB_DEV void bb_normal_pair(unsigned long long seed, unsigned long long q, unsign
     unsigned long long b = ((unsigned long long)o[3] << 32) | o[2];
     double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53;   // (0, 1]
     double u2 = (double)(b >> 11) * 0x1.0p-53;           // [0, 1)
-    double r = sqrt(-2.0 * log(u1));
+    double r = bb_sqrt(-2.0 * bb_log(u1));
     double s, c;
-    bb_sincospi(2.0 * u2, &s, &c);
+    bb_sincospi_02(2.0 * u2, &s, &c);
     *n0 = r * c;
     *n1 = r * s;
 }
 
-BB_DEV void bb_softplus_sigmoid(double om, double* sp, double* sig) {
-    double e = exp(-fabs(om));
-    double inv = 1.0 / (1.0 + e);
-    *sp = fmax(om, 0.0) + log1p(e);
-    *sig = om >= 0.0 ? inv : e * inv;
-}
+BB_DEV void bb_softplus_sigmoid(double om, double* sp, double* sig) { bb_softplus_sigmoid_fast(om, sp, sig); }
 
 BB_DEV void bb_prior_of(const DevModel& M, int blk, long long j, double* mean, double* inv_var) {
     const DevPrior& p = M.pri[blk];
@@ -97,11 +103,11 @@ BB_DEV void bb_prior_of(const DevModel& M, int blk, long long j, double* mean, d
 // LDS carve-up (offsets in doubles) for a tile of NB barcodes worked by nthr threads.
 // ------------------------------------------------------------------------------------------------
 struct BBLds {
-    int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part;
+    int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg;
     int total;
 };
 
-BB_DEV int bb_xdim(const DevModel& M) { return M.kind == 1 ? M.E : M.R; }
+template <int KIND> BB_DEV int bb_xdim(const DevModel& M) { return KIND == 1 ? M.E : M.R; }
 
 static inline
 #ifndef BB_EMU
@@ -131,6 +137,10 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.gglob = o; o += 2 * nt1;
     L.misc = o; o += 16 + BB_MAX_REP;
     L.part = o; o += 32;
+    L.red = o;  o += 16 * K + 8 * BB_NQ * Ttot;   // partial sums of the two-level reductions
+    L.Dt = o;   o += Ttot;
+    L.elbt = o; o += Ttot;
+    L.seg = o;  o += 5 * (BB_MAX_SEG + 1);
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -158,118 +168,217 @@ BB_DEV BBTile bb_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
 }
 
 // which per-unit slot time step t of replicate r uses (environment of t+1 / replicate / 0)
-BB_DEV int bb_xof(const DevModel& M, int r, int t) {
-    return M.kind == 1 ? M.env_idx[t + 1] : (M.kind == 3 ? r : 0);
+template <int KIND> BB_DEV int bb_xof(const DevModel& M, int r, int t) {
+    return KIND == 1 ? M.env_idx[t + 1] : (KIND == 3 ? r : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-latent work over a flat index range [lo, hi), pairs (2q, 2q+1) share one Philox call
+// Segment table: the latents of a tile are a handful of contiguous ranges of the flat vector
+// (loglambda slab per replicate, per-mutant blocks, the replicated global blocks on block 0).
+// All per-latent work runs as ONE flat loop over "pairs" (2q, 2q+1) of those ranges -- a pair shares
+// one Philox call and moves as 16-byte accesses -- so that every thread gets the same share.
 // ------------------------------------------------------------------------------------------------
-// Draw, transform, save (eps, softplus, sigmoid) and hand z to dst(j = i - lo, z).
-// Returns this thread's ELBO terms (prior quadratic + log sigma) when asked.
-template <class Dst>
-BB_DEV double bb_sample_seg(const DevModel& M, const DevState& S, const RunArgs& A, unsigned step, int blk,
-                            long long lo, long long hi, long long t0, long long tstride, bool want_elbo, Dst dst) {
-    double el = 0.0;
-    if (hi <= lo) return el;
-    const long long blo = M.blk_lo[blk];
-    const long long qhi = (hi - 1) >> 1;
-    for (long long q = (lo >> 1) + t0; q <= qhi; q += tstride) {
-        const long long i0 = 2 * q, i1 = i0 + 1;
-        const bool a0 = i0 >= lo, a1 = i1 < hi;
-        double e0, e1;
-        if (S.eps_in) {
-            e0 = a0 ? S.eps_in[(long long)A.sample * M.D + i0] : 0.0;
-            e1 = a1 ? S.eps_in[(long long)A.sample * M.D + i1] : 0.0;
+enum BBSegKind {
+    SK_L = 0,      // loglambda of replicate r             -> zl
+    SK_S,          // s_bc (fitness / multienv)            -> zs0
+    SK_LS_E,       // logsigma_bc (fitness / multienv)     -> zs1
+    SK_TT_G, SK_LT_G, SK_LS_G,            // genotype: theta_tilde -> zs0, logtau -> zs1, logsigma_bc -> zs2
+    SK_TH_R, SK_TT_R, SK_LT_R, SK_LS_R,   // replicate: theta -> zs3, per-replicate tt / lt / ls -> zs0/1/2 + r NB
+    SK_GS, SK_GLS  // global s_pop / logsigma_pop          -> zg (global memory)
+};
+struct BBSeg { long long lo, hi; int pbeg, blk, kind, ldsoff, r, pad; };   // 40 bytes = 5 doubles
+
+BB_DEV int bb_seg_pairs(long long lo, long long hi) { return hi > lo ? (int)(((hi - 1) >> 1) - (lo >> 1) + 1) : 0; }
+
+// Built by one thread; returns the number of segments, sg[n].pbeg = total pairs.
+template <int KIND>
+BB_DEV int bb_build_segs(BBSeg* sg, const DevModel& M, const BBLds& L, const BBTile& t, bool globals) {
+    int n = 0, p = 0;
+    auto add = [&](int blk, int kind, long long lo, long long cnt, int ldsoff, int r) {
+        if (cnt <= 0) return;
+        BBSeg s; s.lo = lo; s.hi = lo + cnt; s.pbeg = p; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.pad = 0;
+        sg[n++] = s;
+        p += bb_seg_pairs(lo, lo + cnt);
+    };
+    for (int r = 0; r < M.R; ++r)
+        add(BK_L, SK_L, M.off_l[r] + t.b0 * M.T[r], (long long)t.nbt * M.T[r], L.zl + t.NB * M.tcum[r], r);
+    if (t.nmt > 0) {
+        if (KIND == 0 || KIND == 1) {
+            const int E = KIND == 1 ? M.E : 1;
+            add(BK_S, SK_S, M.blk_lo[BK_S] + t.m0 * E, (long long)t.nmt * E, L.zs0, 0);
+            add(BK_LS, SK_LS_E, M.blk_lo[BK_LS] + t.m0 * E, (long long)t.nmt * E, L.zs1, 0);
+        } else if (KIND == 2) {
+            add(BK_TT, SK_TT_G, M.blk_lo[BK_TT] + t.m0, t.nmt, L.zs0, 0);
+            add(BK_LT, SK_LT_G, M.blk_lo[BK_LT] + t.m0, t.nmt, L.zs1, 0);
+            add(BK_LS, SK_LS_G, M.blk_lo[BK_LS] + t.m0, t.nmt, L.zs2, 0);
         } else {
-            bb_normal_pair(A.seed, (unsigned long long)q, step, (unsigned)A.sample, &e0, &e1);
+            add(BK_S, SK_TH_R, M.blk_lo[BK_S] + t.m0, t.nmt, L.zs3, 0);
+            for (int r = 0; r < M.R; ++r) {
+                add(BK_TT, SK_TT_R, M.blk_lo[BK_TT] + r * M.nb + t.m0, t.nmt, L.zs0 + r * t.NB, r);
+                add(BK_LT, SK_LT_R, M.blk_lo[BK_LT] + r * M.nb + t.m0, t.nmt, L.zs1 + r * t.NB, r);
+                add(BK_LS, SK_LS_R, M.blk_lo[BK_LS] + r * M.nb + t.m0, t.nmt, L.zs2 + r * t.NB, r);
+            }
         }
-        double mu0 = 0, mu1 = 0, om0 = 0, om1 = 0;
-        if (a0 && a1) {
-            bb_d2 m = *(const bb_d2*)(S.mu + i0), o = *(const bb_d2*)(S.om + i0);
-            mu0 = m.x; mu1 = m.y; om0 = o.x; om1 = o.y;
-        } else if (a0) { mu0 = S.mu[i0]; om0 = S.om[i0]; }
-        else { mu1 = S.mu[i1]; om1 = S.om[i1]; }
-        double sp0, sg0, sp1, sg1;
-        bb_softplus_sigmoid(om0, &sp0, &sg0);
-        bb_softplus_sigmoid(om1, &sp1, &sg1);
-        const double z0 = fma(sp0, e0, mu0), z1 = fma(sp1, e1, mu1);
-        if (a0 && a1) {
-            *(bb_d2*)(S.eps + i0) = bb_d2{e0, e1};
-            *(bb_d2*)(S.sp + i0) = bb_d2{sp0, sp1};
-            *(bb_d2*)(S.sig + i0) = bb_d2{sg0, sg1};
-        } else if (a0) { S.eps[i0] = e0; S.sp[i0] = sp0; S.sig[i0] = sg0; }
-        else { S.eps[i1] = e1; S.sp[i1] = sp1; S.sig[i1] = sg1; }
-        if (a0) dst(i0 - lo, z0);
-        if (a1) dst(i1 - lo, z1);
-        if (want_elbo) {
-            double pm, iv;
-            if (a0) { bb_prior_of(M, blk, i0 - blo, &pm, &iv); el += -0.5 * (z0 - pm) * (z0 - pm) * iv + log(sp0); }
-            if (a1) { bb_prior_of(M, blk, i1 - blo, &pm, &iv); el += -0.5 * (z1 - pm) * (z1 - pm) * iv + log(sp1); }
-        }
+    }
+    if (globals) {
+        add(BK_SPOP, SK_GS, M.blk_lo[BK_SPOP], M.blk_hi[BK_SPOP] - M.blk_lo[BK_SPOP], 0, 0);
+        add(BK_LSPOP, SK_GLS, M.blk_lo[BK_LSPOP], M.blk_hi[BK_LSPOP] - M.blk_lo[BK_LSPOP], 0, 0);
+    }
+    sg[n].pbeg = p;
+    return n;
+}
+
+// f(seg, i0, a0, a1) for every pair of the tile owned by this thread.
+template <class F>
+BB_DEV void bb_for_pairs(const BBCtx& cx, int tid, const BBSeg* sg, int nseg, F f) {
+    const int ptotal = sg[nseg].pbeg;
+    int si = 0;
+    for (int p = tid; p < ptotal; p += cx.nthr) {
+        while (si + 1 < nseg && p >= sg[si + 1].pbeg) ++si;
+        const BBSeg s = sg[si];
+        const long long i0 = 2 * ((s.lo >> 1) + (p - s.pbeg));
+        f(s, i0, i0 >= s.lo, i0 + 1 < s.hi);
+    }
+}
+
+// Draw one pair: eps from Philox (or the caller's buffer), z = mu + softplus(omega) eps; saves what the
+// update sweep needs -- z, a = eps * sigmoid(omega) (= dz/domega) and h = sigmoid/softplus (= dH/domega).
+// Returns the pair's ELBO terms (prior quadratic + log sigma) when asked.
+BB_DEV double bb_sample_pair(const DevModel& M, const DevState& S, const RunArgs& A, unsigned step, int blk,
+                             long long i0, bool a0, bool a1, bool want_elbo, double* z0, double* z1) {
+    const long long i1 = i0 + 1;
+    double e0, e1;
+    if (S.eps_in) {
+        e0 = a0 ? S.eps_in[(long long)A.sample * M.D + i0] : 0.0;
+        e1 = a1 ? S.eps_in[(long long)A.sample * M.D + i1] : 0.0;
+    } else {
+        bb_normal_pair(A.seed, (unsigned long long)(i0 >> 1), step, (unsigned)A.sample, &e0, &e1);
+    }
+    double mu0 = 0, mu1 = 0, om0 = 0, om1 = 0;
+    if (a0 && a1) {
+        const bb_d2 m = *(const bb_d2*)(S.mu + i0), o = *(const bb_d2*)(S.om + i0);
+        mu0 = m.x; mu1 = m.y; om0 = o.x; om1 = o.y;
+    } else if (a0) { mu0 = S.mu[i0]; om0 = S.om[i0]; }
+    else { mu1 = S.mu[i1]; om1 = S.om[i1]; }
+    double sp0, sg0, sp1, sg1;
+    bb_softplus_sigmoid(om0, &sp0, &sg0);
+    bb_softplus_sigmoid(om1, &sp1, &sg1);
+    *z0 = fma(sp0, e0, mu0);
+    *z1 = fma(sp1, e1, mu1);
+    const double h0 = sg0 * bb_rcp(sp0), h1 = sg1 * bb_rcp(sp1);
+    if (a0 && a1) {
+        *(bb_d2*)(S.zsv + i0) = bb_d2{*z0, *z1};
+        *(bb_d2*)(S.asv + i0) = bb_d2{e0 * sg0, e1 * sg1};
+        *(bb_d2*)(S.hsv + i0) = bb_d2{h0, h1};
+    } else if (a0) { S.zsv[i0] = *z0; S.asv[i0] = e0 * sg0; S.hsv[i0] = h0; }
+    else { S.zsv[i1] = *z1; S.asv[i1] = e1 * sg1; S.hsv[i1] = h1; }
+    double el = 0.0;
+    if (want_elbo) {
+        const long long blo = M.blk_lo[blk];
+        double pm, iv;
+        if (a0) { bb_prior_of(M, blk, i0 - blo, &pm, &iv); el += -0.5 * (*z0 - pm) * (*z0 - pm) * iv + bb_log(sp0); }
+        if (a1) { bb_prior_of(M, blk, i1 - blo, &pm, &iv); el += -0.5 * (*z1 - pm) * (*z1 - pm) * iv + bb_log(sp1); }
     }
     return el;
 }
 
-// Rebuild z = mu + softplus(omega) * eps of the saved draw.
-template <class Dst>
-BB_DEV void bb_loadz_seg(const DevState& S, long long lo, long long hi, long long t0, long long tstride, Dst dst) {
-    for (long long i = lo + t0; i < hi; i += tstride) dst(i - lo, fma(S.sp[i], S.eps[i], S.mu[i]));
-}
-
 // One optimiser update of parameter *p with gradient-of-(-ELBO) d.  which: 0 = mu, 1 = omega.
 BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A, unsigned long long step,
-                         int which, long long i, double d, double* p, double* acc) {
+                         int which, long long i, double d, double old_slot, double* new_slot, double* p, double* acc) {
     double upd;
     if (A.opt == 0) {   // TruncatedADAGrad: g2[mod(i-1,n)+1] = d^2; s = sum(g2); d *= eta / (tau + sqrt(s))
         const int slot = (int)(step % (unsigned long long)A.W);
-        double* hs = S.hist + ((long long)slot * 2 + which) * M.D + i;
         const double n2 = d * d;
-        const double old = *hs;
-        *hs = n2;
+        *new_slot = n2;
         double s;
         const bool resum = A.resum_every == 1 || (step > 0 && step % (unsigned long long)A.resum_every == 0);
         if (resum) {
             s = 0.0;
-            for (int j = 0; j < A.W; ++j) s += (j == slot) ? n2 : S.hist[((long long)j * 2 + which) * M.D + i];
+            for (int j = 0; j < A.W; ++j) s += (j == slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
         } else {
-            s = fmax(*acc + n2 - old, 0.0);
+            s = fmax(*acc + n2 - old_slot, 0.0);
         }
         *acc = s;
-        upd = d * (A.eta / (A.tau + sqrt(s)));
+        upd = d * (A.eta * bb_rcp(A.tau + bb_sqrt(s)));
     } else {            // DecayedADAGrad: acc = post*acc + pre*d^2; d *= eta / (sqrt(acc) + 1e-8)
         const double a = A.post * (*acc) + A.pre * d * d;
         *acc = a;
-        upd = d * (A.eta / (sqrt(a) + 1e-8));
+        upd = d * (A.eta * bb_rcp(bb_sqrt(a) + 1e-8));
     }
     *p -= upd;
 }
 
-// Finish one latent: total gradient of the log-joint (likelihood part from glik + prior), the
+// Finish one pair given the likelihood part of d logjoint / d z for its two latents: prior term,
 // reparameterisation gradient w.r.t. (mu, omega), S-sample averaging, entropy term, optimiser.
-template <class Grad>
-BB_DEV void bb_update_seg(const DevModel& M, const DevState& S, const RunArgs& A, unsigned long long step, int blk,
-                          long long lo, long long hi, long long t0, long long tstride, Grad glik) {
-    const long long blo = M.blk_lo[blk];
-    const double invS = 1.0 / (double)A.S;
-    for (long long i = lo + t0; i < hi; i += tstride) {
-        const double mu = S.mu[i], om = S.om[i], e = S.eps[i], sp = S.sp[i], sg = S.sig[i];
-        const double z = fma(sp, e, mu);
-        double pm, iv;
-        bb_prior_of(M, blk, i - blo, &pm, &iv);
-        const double g = glik(i - lo, z) - (z - pm) * iv;   // d logjoint / d z_i
-        double gm = g, go = g * e * sg;
-        if (A.S > 1) {
-            if (!A.first_sample) { gm += S.gacc_mu[i]; go += S.gacc_om[i]; }
-            if (!A.last_sample) { S.gacc_mu[i] = gm; S.gacc_om[i] = go; continue; }
-            gm *= invS; go *= invS;
+BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& A, unsigned long long step, int blk,
+                           long long i0, bool a0, bool a1, double z0, double z1, double gl0, double gl1) {
+    const long long i1 = i0 + 1, blo = M.blk_lo[blk];
+    const bool both = a0 && a1;
+    double pm, iv;
+    double g[2] = {0.0, 0.0};
+    if (a0) { bb_prior_of(M, blk, i0 - blo, &pm, &iv); g[0] = gl0 - (z0 - pm) * iv; }
+    if (a1) { bb_prior_of(M, blk, i1 - blo, &pm, &iv); g[1] = gl1 - (z1 - pm) * iv; }
+    bb_d2 av, hv;
+    if (both) { av = *(const bb_d2*)(S.asv + i0); hv = *(const bb_d2*)(S.hsv + i0); }
+    else if (a0) { av = bb_d2{S.asv[i0], 0.0}; hv = bb_d2{S.hsv[i0], 0.0}; }
+    else { av = bb_d2{0.0, S.asv[i1]}; hv = bb_d2{0.0, S.hsv[i1]}; }
+    double gm[2] = {g[0], g[1]}, go[2] = {g[0] * av.x, g[1] * av.y};
+    if (A.S > 1) {
+        const double invS = 1.0 / (double)A.S;
+        for (int k = 0; k < 2; ++k) {
+            if (!(k ? a1 : a0)) continue;
+            const long long i = i0 + k;
+            if (!A.first_sample) { gm[k] += S.gacc_mu[i]; go[k] += S.gacc_om[i]; }
+            if (!A.last_sample) { S.gacc_mu[i] = gm[k]; S.gacc_om[i] = go[k]; }
+            gm[k] *= invS; go[k] *= invS;
         }
-        go += sg / sp;                                        // d H / d omega
-        if (!A.apply) { S.gacc_mu[i] = gm; S.gacc_om[i] = go; continue; }   // export d ELBO / d theta
-        double pmu = mu, pom = om, am = S.acc_mu[i], ao = S.acc_om[i];
-        bb_opt_apply(M, S, A, step, 0, i, -gm, &pmu, &am);
-        bb_opt_apply(M, S, A, step, 1, i, -go, &pom, &ao);
-        S.mu[i] = pmu; S.om[i] = pom; S.acc_mu[i] = am; S.acc_om[i] = ao;
+        if (!A.last_sample) return;
+    }
+    go[0] += hv.x;                                   // d H / d omega
+    go[1] += hv.y;
+    if (!A.apply) {                                  // export d ELBO / d theta
+        if (a0) { S.gacc_mu[i0] = gm[0]; S.gacc_om[i0] = go[0]; }
+        if (a1) { S.gacc_mu[i1] = gm[1]; S.gacc_om[i1] = go[1]; }
+        return;
+    }
+    bb_d2 mu, om, am, ao, hm = bb_d2{0, 0}, ho = bb_d2{0, 0};
+    double* hs_m = nullptr;
+    double* hs_o = nullptr;
+    if (A.opt == 0) {
+        const int slot = (int)(step % (unsigned long long)A.W);
+        hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dp;
+        hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
+    }
+    if (both) {
+        mu = *(const bb_d2*)(S.mu + i0); om = *(const bb_d2*)(S.om + i0);
+        am = *(const bb_d2*)(S.acc_mu + i0); ao = *(const bb_d2*)(S.acc_om + i0);
+        if (hs_m) { hm = *(const bb_d2*)(hs_m + i0); ho = *(const bb_d2*)(hs_o + i0); }
+    } else {
+        const long long i = a0 ? i0 : i1;
+        const double m_ = S.mu[i], o_ = S.om[i], am_ = S.acc_mu[i], ao_ = S.acc_om[i];
+        const double hm_ = hs_m ? hs_m[i] : 0.0, ho_ = hs_o ? hs_o[i] : 0.0;
+        mu = a0 ? bb_d2{m_, 0} : bb_d2{0, m_}; om = a0 ? bb_d2{o_, 0} : bb_d2{0, o_};
+        am = a0 ? bb_d2{am_, 0} : bb_d2{0, am_}; ao = a0 ? bb_d2{ao_, 0} : bb_d2{0, ao_};
+        hm = a0 ? bb_d2{hm_, 0} : bb_d2{0, hm_}; ho = a0 ? bb_d2{ho_, 0} : bb_d2{0, ho_};
+    }
+    bb_d2 nhm = hm, nho = ho;
+    if (a0) {
+        bb_opt_apply(M, S, A, step, 0, i0, -gm[0], hm.x, &nhm.x, &mu.x, &am.x);
+        bb_opt_apply(M, S, A, step, 1, i0, -go[0], ho.x, &nho.x, &om.x, &ao.x);
+    }
+    if (a1) {
+        bb_opt_apply(M, S, A, step, 0, i1, -gm[1], hm.y, &nhm.y, &mu.y, &am.y);
+        bb_opt_apply(M, S, A, step, 1, i1, -go[1], ho.y, &nho.y, &om.y, &ao.y);
+    }
+    if (both) {
+        *(bb_d2*)(S.mu + i0) = mu; *(bb_d2*)(S.om + i0) = om;
+        *(bb_d2*)(S.acc_mu + i0) = am; *(bb_d2*)(S.acc_om + i0) = ao;
+        if (hs_m) { *(bb_d2*)(hs_m + i0) = nhm; *(bb_d2*)(hs_o + i0) = nho; }
+    } else {
+        const long long i = a0 ? i0 : i1;
+        S.mu[i] = a0 ? mu.x : mu.y; S.om[i] = a0 ? om.x : om.y;
+        S.acc_mu[i] = a0 ? am.x : am.y; S.acc_om[i] = a0 ? ao.x : ao.y;
+        if (hs_m) { hs_m[i] = a0 ? nhm.x : nhm.y; hs_o[i] = a0 ? nho.x : nho.y; }
     }
 }
 
@@ -295,15 +404,16 @@ BB_DEV void bb_row_sum(BBCtx& cx, const double* row, int n, double* part16, doub
 }
 
 // Per-unit effective fitness and precision tables for the tile (slot = bl * X + x):
-//   fitness   s_eff = s_bc                          w = exp(-2 logsigma_bc)      model_fitness_normal.jl:262-270
+//   fitness   s_eff = s_bc                          w = bb_exp(-2 logsigma_bc)      model_fitness_normal.jl:262-270
 //   multienv  s_eff[e] = s_bc[e, m]                 w[e] likewise                model_multienv_fitness_normal.jl:293-301
-//   genotype  s_eff = theta[geno] + exp(logtau)*tt                               ..._genotypes.jl:230
-//   replicate s_eff[r] = theta + exp(logtau_r)*tt_r                              ..._replicates.jl:216
+//   genotype  s_eff = theta[geno] + bb_exp(logtau)*tt                               ..._genotypes.jl:230
+//   replicate s_eff[r] = theta + bb_exp(logtau_r)*tt_r                              ..._replicates.jl:216
 // Returns the thread's ELBO term  - sum_units logsigma_eff * (#time steps using the slot).
+template <int KIND>
 BB_DEV double bb_effective_tables(BBCtx& cx, int tid, const DevModel& M, const DevState& S, const BBLds& L,
                                   const BBTile& t, bool want_elbo) {
     double* lds = cx.lds;
-    const int X = bb_xdim(M);
+    const int X = bb_xdim<KIND>(M);
     double el = 0.0;
     for (int u = tid; u < t.nbt * X; u += cx.nthr) {
         const int bl = u / X, x = u - bl * X;
@@ -311,20 +421,20 @@ BB_DEV double bb_effective_tables(BBCtx& cx, int tid, const DevModel& M, const D
         if (bl >= t.nshift) {
             const int ml = bl - t.nshift;
             double ls;
-            if (M.kind == 0) { se = lds[L.zs0 + ml]; ls = lds[L.zs1 + ml]; }
-            else if (M.kind == 1) { se = lds[L.zs0 + ml * X + x]; ls = lds[L.zs1 + ml * X + x]; }
-            else if (M.kind == 2) {
-                se = S.ztheta[M.geno_idx[t.m0 + ml]] + exp(lds[L.zs1 + ml]) * lds[L.zs0 + ml];
+            if (KIND == 0) { se = lds[L.zs0 + ml]; ls = lds[L.zs1 + ml]; }
+            else if (KIND == 1) { se = lds[L.zs0 + ml * X + x]; ls = lds[L.zs1 + ml * X + x]; }
+            else if (KIND == 2) {
+                se = S.ztheta[M.geno_idx[t.m0 + ml]] + bb_exp(lds[L.zs1 + ml]) * lds[L.zs0 + ml];
                 ls = lds[L.zs2 + ml];
             } else {
-                se = lds[L.zs3 + ml] + exp(lds[L.zs1 + x * t.NB + ml]) * lds[L.zs0 + x * t.NB + ml];
+                se = lds[L.zs3 + ml] + bb_exp(lds[L.zs1 + x * t.NB + ml]) * lds[L.zs0 + x * t.NB + ml];
                 ls = lds[L.zs2 + x * t.NB + ml];
             }
-            we = exp(-2.0 * ls);
+            we = bb_exp(-2.0 * ls);
             if (want_elbo) {
                 int cnt;
-                if (M.kind == 1) { cnt = 0; for (int tt = 0; tt < M.T[0] - 1; ++tt) cnt += (M.env_idx[tt + 1] == x); }
-                else cnt = M.T[M.kind == 3 ? x : 0] - 1;
+                if (KIND == 1) { cnt = 0; for (int tt = 0; tt < M.T[0] - 1; ++tt) cnt += (M.env_idx[tt + 1] == x); }
+                else cnt = M.T[KIND == 3 ? x : 0] - 1;
                 el -= ls * cnt;
             }
         }
@@ -334,75 +444,55 @@ BB_DEV double bb_effective_tables(BBCtx& cx, int tid, const DevModel& M, const D
     return el;
 }
 
-// Stage the tile's latent samples into LDS.  SAMPLE = draw them; otherwise rebuild the saved draw.
-template <bool SAMPLE>
-BB_DEV double bb_stage_tile(BBCtx& cx, int tid, const DevModel& M, const DevState& S, const RunArgs& A,
-                            const BBLds& L, const BBTile& t, unsigned step, bool want_elbo) {
-    double* lds = cx.lds;
-    double el = 0.0;
-    auto seg = [&](int blk, long long lo, long long n, int ldsoff) {
-        auto dst = [&](long long j, double z) { lds[ldsoff + j] = z; };
-        if (SAMPLE) el += bb_sample_seg(M, S, A, step, blk, lo, lo + n, tid, cx.nthr, want_elbo, dst);
-        else bb_loadz_seg(S, lo, lo + n, tid, cx.nthr, dst);
-    };
-    for (int r = 0; r < M.R; ++r)
-        seg(BK_L, M.off_l[r] + t.b0 * M.T[r], (long long)t.nbt * M.T[r], L.zl + t.NB * M.tcum[r]);
-    if (t.nmt > 0) {
-        if (M.kind == 0) {
-            seg(BK_S, M.blk_lo[BK_S] + t.m0, t.nmt, L.zs0);
-            seg(BK_LS, M.blk_lo[BK_LS] + t.m0, t.nmt, L.zs1);
-        } else if (M.kind == 1) {
-            seg(BK_S, M.blk_lo[BK_S] + t.m0 * M.E, (long long)t.nmt * M.E, L.zs0);
-            seg(BK_LS, M.blk_lo[BK_LS] + t.m0 * M.E, (long long)t.nmt * M.E, L.zs1);
-        } else if (M.kind == 2) {
-            seg(BK_TT, M.blk_lo[BK_TT] + t.m0, t.nmt, L.zs0);
-            seg(BK_LT, M.blk_lo[BK_LT] + t.m0, t.nmt, L.zs1);
-            seg(BK_LS, M.blk_lo[BK_LS] + t.m0, t.nmt, L.zs2);
-        } else {
-            seg(BK_S, M.blk_lo[BK_S] + t.m0, t.nmt, L.zs3);
-            for (int r = 0; r < M.R; ++r) {
-                seg(BK_TT, M.blk_lo[BK_TT] + r * M.nb + t.m0, t.nmt, L.zs0 + r * t.NB);
-                seg(BK_LT, M.blk_lo[BK_LT] + r * M.nb + t.m0, t.nmt, L.zs1 + r * t.NB);
-                seg(BK_LS, M.blk_lo[BK_LS] + r * M.nb + t.m0, t.nmt, L.zs2 + r * t.NB);
-            }
-        }
-    }
-    return el;
-}
-
 // ================================================================================================
 // block_sample: sampling sweep + partial moments of one tile
 // ================================================================================================
+template <int KIND>
 BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
-    const BBLds L = bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const unsigned step = (unsigned)S.ctr[A.par];
-    const int X = bb_xdim(M);
+    const int X = bb_xdim<KIND>(M);
     const bool we = A.with_elbo != 0;
 
-    // pass S: draw every latent of the tile (block 0 also draws the replicated global latents)
+    BB_STAMP(cx, S, 0);
+    BBSeg* sg = (BBSeg*)(lds + L.seg);
+    int* li = (int*)(lds + L.misc);
     BB_PASS(cx, tid) {
-        double el = bb_stage_tile<true>(cx, tid, M, S, A, L, t, step, we);
-        if (cx.block == 0) {
-            double eg = 0.0;
-            eg += bb_sample_seg(M, S, A, step, BK_SPOP, M.blk_lo[BK_SPOP], M.blk_hi[BK_SPOP], tid, cx.nthr, we,
-                                [&](long long j, double z) { S.zg[j] = z; });
-            eg += bb_sample_seg(M, S, A, step, BK_LSPOP, M.blk_lo[BK_LSPOP], M.blk_hi[BK_LSPOP], tid, cx.nthr, we,
-                                [&](long long j, double z) { S.zg[M.nt1 + j] = z; });
-            if (A.count_globals) el += eg;
-        }
-        lds[L.acc + BB_NQ * cx.nthr + tid] = el;
+        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
         for (int k = tid; k < M.K; k += cx.nthr) lds[L.wk + k] = 0.0;
     }
     BB_SYNC(cx);
+    // pass S: draw every latent of the tile (block 0 also draws the replicated global latents)
+    BB_PASS(cx, tid) {
+        double el = 0.0;
+        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
+            double z0, z1;
+            const double e = bb_sample_pair(M, S, A, step, s.blk, i0, a0, a1, we, &z0, &z1);
+            if (s.kind >= SK_GS) {
+                double* zg = S.zg + (s.kind == SK_GLS ? M.nt1 : 0);
+                if (a0) zg[i0 - s.lo] = z0;
+                if (a1) zg[i0 + 1 - s.lo] = z1;
+                if (A.count_globals) el += e;
+            } else {
+                if (a0) lds[s.ldsoff + (i0 - s.lo)] = z0;
+                if (a1) lds[s.ldsoff + (i0 + 1 - s.lo)] = z1;
+                el += e;
+            }
+        });
+        lds[L.acc + BB_NQ * cx.nthr + tid] = el;
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 1);
 
     // pass E: effective fitness / precision per unit
     BB_PASS(cx, tid) {
-        double el = bb_effective_tables(cx, tid, M, S, L, t, we);
+        double el = bb_effective_tables<KIND>(cx, tid, M, S, L, t, we);
         lds[L.acc + BB_NQ * cx.nthr + tid] += el;
     }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 2);
 
     // pass M: per replicate, every (barcode, time) element contributes to the moments of its time
     for (int r = 0; r < M.R; ++r) {
@@ -414,10 +504,10 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
             if (tid < nact) {
                 const int blq = (int)bb_umulhi((unsigned)tid, M.Tmagic[r]);
                 const int tt = tid - blq * T;
-                const int x = (tt < T - 1) ? bb_xof(M, r, tt) : 0;
+                const int x = (tt < T - 1) ? bb_xof<KIND>(M, r, tt) : 0;
                 for (int bl = blq; bl < t.nbt; bl += bstride) {
                     const double z = zl[bl * T + tt];
-                    const double lam = exp(z);
+                    const double lam = bb_exp(z);
                     aS += lam;
                     if (we) el += (double)M.counts[M.cnt_off[r] + (t.b0 + bl) * T + tt] * z - lam;
                     if (tt < T - 1) {
@@ -438,67 +528,130 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
             acc[BB_NQ * cx.nthr + tid] += el;
         }
         BB_SYNC(cx);
+        BB_STAMP(cx, S, 3);
+        // column sums per (quantity, time): 8 strided partial sums per column, then one add chain
         BB_PASS(cx, tid) {
+            double* tmp = lds + L.red;
+            for (int w = tid; w < BB_NQ * T * 8; w += cx.nthr) {
+                const int j = w >> 3, c = w & 7;
+                const int q = (int)bb_umulhi((unsigned)j, M.Tmagic[r]);
+                const int tt = j - q * T;
+                const double* row = lds + L.acc + q * cx.nthr + tt;
+                double s = 0.0;
+                for (int i = c; i < bstride; i += 8) s += row[T * i];
+                tmp[w] = s;
+            }
+        }
+        BB_SYNC(cx);
+        BB_PASS(cx, tid) {
+            const double* tmp = lds + L.red;
             for (int j = tid; j < BB_NQ * T; j += cx.nthr) {
                 const int q = (int)bb_umulhi((unsigned)j, M.Tmagic[r]);
                 const int tt = j - q * T;
                 if (q == 0 || tt < T - 1) {
-                    const double* row = lds + L.acc + q * cx.nthr;
                     double s = 0.0;
-                    for (int i = 0; i < bstride; ++i) s += row[tt + T * i];
+                    for (int c = 0; c < 8; ++c) s += tmp[j * 8 + c];
                     lds[L.wk + (q == 0 ? M.kq[r] + tt : M.kq[r] + T + 5 * tt + (q - 1))] = s;
                 }
             }
         }
         BB_SYNC(cx);
     }
-    bb_row_sum(cx, lds + L.acc + BB_NQ * cx.nthr, cx.nthr, lds + L.part, lds + L.wk + (M.K - 2));
+    BB_STAMP(cx, S, 4);
+    if (we) bb_row_sum(cx, lds + L.acc + BB_NQ * cx.nthr, cx.nthr, lds + L.part, lds + L.wk + (M.K - 2));
+    BB_STAMP(cx, S, 5);
     BB_PASS(cx, tid) {
         for (int k = tid; k < M.K; k += cx.nthr) S.partials[(long long)k * A.nblk + cx.block] = lds[L.wk + k];
     }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 6);
 }
 
 // Sum the moment rows and finish everything that depends on them (per replicate, tiny).
 BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L) {
     double* lds = cx.lds;
+    // two-level, fixed-order sum of each moment row: 16 strided partial sums, then one add chain
+    if (A.nred > 1) {
+        double* tmp = lds + L.red;
+        BB_PASS(cx, tid) {
+            for (int w = tid; w < M.K * 16; w += cx.nthr) {
+                const int k = w >> 4, c = w & 15;
+                const double* row = A.red + (long long)k * A.nred;
+                double s = 0.0;
+                for (int j0 = c; j0 < A.nred; j0 += 128) {   // 8 independent loads in flight, fixed add tree
+                    double v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (j0 + 16 * i < A.nred) ? row[j0 + 16 * i] : 0.0;
+                    s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                }
+                tmp[w] = s;
+            }
+        }
+        BB_SYNC(cx);
+        BB_PASS(cx, tid) {
+            for (int k = tid; k < M.K; k += cx.nthr) {
+                double s = 0.0;
+                for (int c = 0; c < 16; ++c) s += tmp[k * 16 + c];
+                lds[L.wk + k] = s;
+            }
+        }
+    } else {
+        BB_PASS(cx, tid) {
+            for (int k = tid; k < M.K; k += cx.nthr) lds[L.wk + k] = A.red[k];
+        }
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 9);
+    // everything that depends on the totals, one (replicate, time) item per thread
     BB_PASS(cx, tid) {
-        for (int k = tid; k < M.K; k += cx.nthr) {
-            double s = 0.0;
-            for (int j = 0; j < A.nred; ++j) s += A.red[(long long)k * A.nred + j];
-            lds[L.wk + k] = s;
+        for (int j = tid; j < M.Ttot; j += cx.nthr) {
+            int r = 0;
+            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
+            const int tt = j - M.tcum[r];
+            const double St = lds[L.wk + M.kq[r] + tt];
+            lds[L.invS + j] = bb_rcp(St);
+            lds[L.Lt + j] = bb_log(St);
         }
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
-        if (tid < M.R) {
-            const int r = tid, T = M.T[r], tc = M.tcum[r], kq = M.kq[r];
-            const double nn = (double)M.nn;
-            for (int tt = 0; tt < T; ++tt) {
-                const double St = lds[L.wk + kq + tt];
-                lds[L.invS + tc + tt] = 1.0 / St;
-                lds[L.Lt + tc + tt] = log(St);
-            }
-            double Dprev = 0.0, elb = 0.0;
-            for (int tt = 0; tt < T - 1; ++tt) {
-                const double* mm = lds + L.wk + kq + T + 5 * tt;
+        for (int j = tid; j < M.Ttot; j += cx.nthr) {
+            int r = 0;
+            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
+            const int tt = j - M.tcum[r], T = M.T[r];
+            double Dt = 0.0, elb = 0.0;
+            if (tt < T - 1) {
+                const double nn = (double)M.nn;
+                const double* mm = lds + L.wk + M.kq[r] + T + 5 * tt;
                 const double M0 = mm[0], M1 = mm[1], M2 = mm[2], N1 = mm[3], N2 = mm[4];
                 const double sbar = S.zg[M.off_t[r] + tt], ls = S.zg[M.nt1 + M.off_t[r] + tt];
-                const double wb = exp(-2.0 * ls);
-                const double c = lds[L.Lt + tc + tt + 1] - lds[L.Lt + tc + tt] - sbar;
+                const double wb = bb_exp(-2.0 * ls);
+                const double c = lds[L.Lt + j + 1] - lds[L.Lt + j] - sbar;
                 const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
                 const double quadM = M2 - 2.0 * c * M1 + c * c * M0;
-                const double Dt = (M1 - c * M0) + wb * (N1 - c * nn);
+                Dt = (M1 - c * M0) + wb * (N1 - c * nn);
                 lds[L.gglob + M.off_t[r] + tt] = -Dt;
                 lds[L.gglob + M.nt1 + M.off_t[r] + tt] = wb * quadN - nn;
-                lds[L.GG + tc + tt] = Dprev - Dt;
-                Dprev = Dt;
-                lds[L.cc + tc + tt] = c;
-                lds[L.wbar + tc + tt] = wb;
-                elb += -0.5 * (quadM + wb * quadN) - nn * ls;
+                lds[L.cc + j] = c;
+                lds[L.wbar + j] = wb;
+                elb = -0.5 * (quadM + wb * quadN) - nn * ls;
             }
-            lds[L.GG + tc + T - 1] = Dprev;
-            lds[L.misc + 16 + r] = elb;
+            lds[L.Dt + j] = Dt;
+            lds[L.elbt + j] = elb;
+        }
+    }
+    BB_SYNC(cx);
+    BB_PASS(cx, tid) {
+        for (int j = tid; j < M.Ttot; j += cx.nthr) {
+            int r = 0;
+            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
+            const int tt = j - M.tcum[r];
+            lds[L.GG + j] = (tt > 0 ? lds[L.Dt + j - 1] : 0.0) - lds[L.Dt + j];   // Dt == 0 at tt == T-1
+        }
+        if (tid < M.R) {
+            double e = 0.0;
+            for (int tt = 0; tt < M.T[tid] - 1; ++tt) e += lds[L.elbt + M.tcum[tid] + tt];
+            lds[L.misc + 16 + tid] = e;
         }
     }
     BB_SYNC(cx);
@@ -507,19 +660,41 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
 // ================================================================================================
 // block_update: gradient of the log-joint for the tile's latents + optimiser step
 // ================================================================================================
+template <int KIND>
 BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
-    const BBLds L = bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const unsigned long long step = S.ctr[A.par];
-    const int X = bb_xdim(M);
+    const int X = bb_xdim<KIND>(M);
 
+    BB_STAMP(cx, S, 8);
     bb_finalize(cx, M, S, A, L);
+    BB_STAMP(cx, S, 10);
 
-    BB_PASS(cx, tid) { bb_stage_tile<false>(cx, tid, M, S, A, L, t, (unsigned)step, false); }
+    BBSeg* sg = (BBSeg*)(lds + L.seg);
+    int* li = (int*)(lds + L.misc);
+    BB_PASS(cx, tid) {
+        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
+    }
     BB_SYNC(cx);
-    BB_PASS(cx, tid) { bb_effective_tables(cx, tid, M, S, L, t, false); }
+    // stage: the saved draw of every tile latent back into LDS
+    BB_PASS(cx, tid) {
+        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
+            if (s.kind >= SK_GS) return;
+            if (a0 && a1) {
+                const bb_d2 z = *(const bb_d2*)(S.zsv + i0);
+                lds[s.ldsoff + (i0 - s.lo)] = z.x;
+                lds[s.ldsoff + (i0 + 1 - s.lo)] = z.y;
+            } else if (a0) lds[s.ldsoff + (i0 - s.lo)] = S.zsv[i0];
+            else lds[s.ldsoff + (i0 + 1 - s.lo)] = S.zsv[i0 + 1];
+        });
+    }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 11);
+    BB_PASS(cx, tid) { bb_effective_tables<KIND>(cx, tid, M, S, L, t, false); }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 12);
 
     // pass R: residuals r = (l[t+1] - l[t]) - s_eff - c_t of every (barcode, time step)
     for (int r = 0; r < M.R; ++r) {
@@ -531,12 +706,13 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
             for (int j = tid; j < t.nbt * T1; j += cx.nthr) {
                 const int bl = T1 == 1 ? j : (int)bb_umulhi((unsigned)j, magic1), tt = j - bl * T1;
                 double a = zl[bl * T + tt + 1] - zl[bl * T + tt];
-                if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof(M, r, tt)];
+                if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof<KIND>(M, r, tt)];
                 res[j] = a - lds[L.cc + tc + tt];
             }
         }
     }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 13);
 
     // pass U: per-unit sums  As = sum_t w r  (= dlogp/ds_eff),  Qs = sum_t (w r^2 - 1)  (= dlogp/dlogsigma_eff)
     BB_PASS(cx, tid) {
@@ -545,92 +721,76 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
             double as = 0.0, qs = 0.0;
             if (bl >= t.nshift) {
                 const double w = lds[L.weff + u];
-                const int r = M.kind == 3 ? x : 0;
+                const int r = KIND == 3 ? x : 0;
                 const int T1 = M.T[r] - 1;
                 const double* res = lds + L.res + NB * (M.tcum[r] - r) + bl * T1;
                 for (int tt = 0; tt < T1; ++tt) {
-                    if (M.kind == 1 && M.env_idx[tt + 1] != x) continue;
+                    if (KIND == 1 && M.env_idx[tt + 1] != x) continue;
                     const double rr = res[tt];
                     as += w * rr;
                     qs += w * rr * rr - 1.0;
                 }
-                if (M.kind == 2) S.ds[t.m0 + (bl - t.nshift)] = as;
+                if (KIND == 2) S.ds[t.m0 + (bl - t.nshift)] = as;
             }
             lds[L.As + u] = as;
             lds[L.Qs + u] = qs;
         }
     }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 14);
 
-    // pass G: gather each latent's gradient and update it
-    const bool do_update = true;
+    // pass G: gather each latent's likelihood gradient from the LDS tables and update it
     BB_PASS(cx, tid) {
-        if (do_update) {
-            for (int r = 0; r < M.R; ++r) {
-                const int T = M.T[r], T1 = T - 1, tc = M.tcum[r];
+        const int ns = t.nshift;
+        auto glik = [&](const BBSeg& s, long long j, double z) -> double {
+            switch (s.kind) {
+            case SK_L: {
+                const int r = s.r, T = M.T[r], T1 = T - 1, tc = M.tcum[r];
                 const double* res = lds + L.res + NB * (tc - r);
-                const long long lo = M.off_l[r] + t.b0 * T;
-                const unsigned* cnt = M.counts + M.cnt_off[r] + t.b0 * T;
-                bb_update_seg(M, S, A, step, BK_L, lo, lo + (long long)t.nbt * T, tid, cx.nthr,
-                              [&](long long j, double z) {
-                                  const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
-                                  const bool mut = bl >= t.nshift;
-                                  const double lam = exp(z);
-                                  double g = (double)cnt[j] - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
-                                  if (tt < T1) {
-                                      const double w = mut ? lds[L.weff + bl * X + bb_xof(M, r, tt)] : lds[L.wbar + tc + tt];
-                                      g += w * res[bl * T1 + tt];
-                                  }
-                                  if (tt > 0) {
-                                      const double w = mut ? lds[L.weff + bl * X + bb_xof(M, r, tt - 1)] : lds[L.wbar + tc + tt - 1];
-                                      g -= w * res[bl * T1 + tt - 1];
-                                  }
-                                  return g;
-                              });
-            }
-            if (t.nmt > 0) {
-                const int ns = t.nshift;
-                if (M.kind == 0 || M.kind == 1) {
-                    const int E = M.kind == 1 ? M.E : 1;
-                    bb_update_seg(M, S, A, step, BK_S, M.blk_lo[BK_S] + t.m0 * E, M.blk_lo[BK_S] + (t.m0 + t.nmt) * E,
-                                  tid, cx.nthr, [&](long long j, double) { return lds[L.As + ns * E + j]; });
-                    bb_update_seg(M, S, A, step, BK_LS, M.blk_lo[BK_LS] + t.m0 * E, M.blk_lo[BK_LS] + (t.m0 + t.nmt) * E,
-                                  tid, cx.nthr, [&](long long j, double) { return lds[L.Qs + ns * E + j]; });
-                } else if (M.kind == 2) {
-                    bb_update_seg(M, S, A, step, BK_TT, M.blk_lo[BK_TT] + t.m0, M.blk_lo[BK_TT] + t.m0 + t.nmt, tid, cx.nthr,
-                                  [&](long long j, double) { return lds[L.As + ns + j] * exp(lds[L.zs1 + j]); });
-                    bb_update_seg(M, S, A, step, BK_LT, M.blk_lo[BK_LT] + t.m0, M.blk_lo[BK_LT] + t.m0 + t.nmt, tid, cx.nthr,
-                                  [&](long long j, double z) { return lds[L.As + ns + j] * exp(z) * lds[L.zs0 + j]; });
-                    bb_update_seg(M, S, A, step, BK_LS, M.blk_lo[BK_LS] + t.m0, M.blk_lo[BK_LS] + t.m0 + t.nmt, tid, cx.nthr,
-                                  [&](long long j, double) { return lds[L.Qs + ns + j]; });
-                } else {
-                    const int R = M.R;
-                    bb_update_seg(M, S, A, step, BK_S, M.blk_lo[BK_S] + t.m0, M.blk_lo[BK_S] + t.m0 + t.nmt, tid, cx.nthr,
-                                  [&](long long j, double) {
-                                      double s = 0.0;
-                                      for (int r = 0; r < R; ++r) s += lds[L.As + (ns + j) * R + r];
-                                      return s;
-                                  });
-                    for (int r = 0; r < R; ++r) {
-                        const long long o = (long long)r * M.nb + t.m0;
-                        bb_update_seg(M, S, A, step, BK_TT, M.blk_lo[BK_TT] + o, M.blk_lo[BK_TT] + o + t.nmt, tid, cx.nthr,
-                                      [&](long long j, double) { return lds[L.As + (ns + j) * R + r] * exp(lds[L.zs1 + r * NB + j]); });
-                        bb_update_seg(M, S, A, step, BK_LT, M.blk_lo[BK_LT] + o, M.blk_lo[BK_LT] + o + t.nmt, tid, cx.nthr,
-                                      [&](long long j, double z) { return lds[L.As + (ns + j) * R + r] * exp(z) * lds[L.zs0 + r * NB + j]; });
-                        bb_update_seg(M, S, A, step, BK_LS, M.blk_lo[BK_LS] + o, M.blk_lo[BK_LS] + o + t.nmt, tid, cx.nthr,
-                                      [&](long long j, double) { return lds[L.Qs + (ns + j) * R + r]; });
-                    }
+                const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
+                const bool mut = bl >= ns;
+                const double lam = bb_exp(z);
+                const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
+                double g = cnt - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
+                if (tt < T1) {
+                    const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)] : lds[L.wbar + tc + tt];
+                    g += w * res[bl * T1 + tt];
                 }
+                if (tt > 0) {
+                    const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)] : lds[L.wbar + tc + tt - 1];
+                    g -= w * res[bl * T1 + tt - 1];
+                }
+                return g;
             }
-            if (cx.block == 0) {   // replicated global latents: every rank applies the identical update
-                bb_update_seg(M, S, A, step, BK_SPOP, M.blk_lo[BK_SPOP], M.blk_hi[BK_SPOP], tid, cx.nthr,
-                              [&](long long j, double) { return lds[L.gglob + j]; });
-                bb_update_seg(M, S, A, step, BK_LSPOP, M.blk_lo[BK_LSPOP], M.blk_hi[BK_LSPOP], tid, cx.nthr,
-                              [&](long long j, double) { return lds[L.gglob + M.nt1 + j]; });
+            case SK_S: return lds[L.As + ns * X + j];
+            case SK_LS_E: return lds[L.Qs + ns * X + j];
+            case SK_TT_G: return lds[L.As + ns + j] * bb_exp(lds[L.zs1 + j]);
+            case SK_LT_G: return lds[L.As + ns + j] * bb_exp(z) * lds[L.zs0 + j];
+            case SK_LS_G: return lds[L.Qs + ns + j];
+            case SK_TH_R: {
+                double a = 0.0;
+                for (int r = 0; r < M.R; ++r) a += lds[L.As + (ns + j) * M.R + r];
+                return a;
             }
-        }
+            case SK_TT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(lds[L.zs1 + s.r * NB + j]);
+            case SK_LT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(z) * lds[L.zs0 + s.r * NB + j];
+            case SK_LS_R: return lds[L.Qs + (ns + j) * M.R + s.r];
+            case SK_GS: return lds[L.gglob + j];
+            default: return lds[L.gglob + M.nt1 + j];
+            }
+        };
+        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
+            double z0 = 0.0, z1 = 0.0;
+            if (a0 && a1) { const bb_d2 z = *(const bb_d2*)(S.zsv + i0); z0 = z.x; z1 = z.y; }
+            else if (a0) z0 = S.zsv[i0];
+            else z1 = S.zsv[i0 + 1];
+            const double g0 = a0 ? glik(s, i0 - s.lo, z0) : 0.0;
+            const double g1 = a1 ? glik(s, i0 + 1 - s.lo, z1) : 0.0;
+            bb_update_pair(M, S, A, step, s.blk, i0, a0, a1, z0, z1, g0, g1);
+        });
     }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 15);
 
     BB_PASS(cx, tid) {
         if (cx.block == 0 && tid == 0) {
@@ -647,6 +807,7 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
         }
     }
     BB_SYNC(cx);
+    BB_STAMP(cx, S, 16);
 }
 
 // ================================================================================================
@@ -655,22 +816,33 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
 // update (optional) then sample theta; gsum[g] = sum of ds over the genotype's mutants.
 BB_DEV void bb_block_geno(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int nblocks,
                           int do_update, int do_sample, int upd_par) {
-    const long long gt0 = (long long)cx.block * cx.nthr, gstride = (long long)nblocks * cx.nthr;
     double* lds = cx.lds;
+    const long long lo = M.blk_lo[BK_S], hi = M.blk_hi[BK_S];
+    const int npairs = bb_seg_pairs(lo, hi);
     if (do_update) {
         const unsigned long long step = S.ctr[upd_par];
-        RunArgs Au = A;
         BB_PASS(cx, tid) {
-            bb_update_seg(M, S, Au, step, BK_S, M.blk_lo[BK_S], M.blk_hi[BK_S], gt0 + tid, gstride,
-                          [&](long long j, double) { return S.gsum[j]; });
+            for (long long p = (long long)cx.block * cx.nthr + tid; p < npairs; p += (long long)nblocks * cx.nthr) {
+                const long long i0 = 2 * ((lo >> 1) + p);
+                const bool a0 = i0 >= lo, a1 = i0 + 1 < hi;
+                const double z0 = a0 ? S.zsv[i0] : 0.0, z1 = a1 ? S.zsv[i0 + 1] : 0.0;
+                bb_update_pair(M, S, A, step, BK_S, i0, a0, a1, z0, z1, a0 ? S.gsum[i0 - lo] : 0.0, a1 ? S.gsum[i0 + 1 - lo] : 0.0);
+            }
         }
         BB_SYNC(cx);
     }
     if (do_sample) {
         const unsigned step = (unsigned)S.ctr[A.par];
         BB_PASS(cx, tid) {
-            double el = bb_sample_seg(M, S, A, step, BK_S, M.blk_lo[BK_S], M.blk_hi[BK_S], gt0 + tid, gstride,
-                                      A.with_elbo != 0, [&](long long j, double z) { S.ztheta[j] = z; });
+            double el = 0.0;
+            for (long long p = (long long)cx.block * cx.nthr + tid; p < npairs; p += (long long)nblocks * cx.nthr) {
+                const long long i0 = 2 * ((lo >> 1) + p);
+                const bool a0 = i0 >= lo, a1 = i0 + 1 < hi;
+                double z0, z1;
+                el += bb_sample_pair(M, S, A, step, BK_S, i0, a0, a1, A.with_elbo != 0, &z0, &z1);
+                if (a0) S.ztheta[i0 - lo] = z0;
+                if (a1) S.ztheta[i0 + 1 - lo] = z1;
+            }
             lds[tid] = el;
         }
         BB_SYNC(cx);

@@ -92,13 +92,22 @@ static int dsync(bbStream s) { BB_HIP(hipStreamSynchronize(s)); return 0; }
 
 extern __shared__ __attribute__((aligned(16))) double bb_smem[];
 
+template <int KIND>
 __global__ void __launch_bounds__(1024) k_sample(DevModel M, DevState S, RunArgs A, int NB) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
-    bb_block_sample(cx, M, S, A, NB);
+    bb_block_sample<KIND>(cx, M, S, A, NB);
 }
+template <int KIND>
 __global__ void __launch_bounds__(1024) k_update(DevModel M, DevState S, RunArgs A, int NB) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
-    bb_block_update(cx, M, S, A, NB);
+    bb_block_update<KIND>(cx, M, S, A, NB);
+}
+typedef void (*bb_step_kernel)(DevModel, DevState, RunArgs, int);
+static bb_step_kernel sample_kernel(int kind) {
+    switch (kind) { case 0: return k_sample<0>; case 1: return k_sample<1>; case 2: return k_sample<2>; default: return k_sample<3>; }
+}
+static bb_step_kernel update_kernel(int kind) {
+    switch (kind) { case 0: return k_update<0>; case 1: return k_update<1>; case 2: return k_update<2>; default: return k_update<3>; }
 }
 __global__ void __launch_bounds__(256) k_geno(DevModel M, DevState S, RunArgs A, int do_update, int do_sample, int upd_par) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
@@ -358,6 +367,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     }
     add_block(h, "loglambda", BK_L, n_l, &off);
     M.D = off;
+    M.Dp = (off + 7) & ~7ll;
     for (int r = 0, o = 0; r < M.R; ++r) { M.off_l[r] = M.blk_lo[BK_L] + (long long)o * M.B; o += M.T[r]; }
 
     // ---- counts: validate totals == row sums (Multinomial support, Distributions.jl), to uint32
@@ -477,8 +487,8 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         h->ngeno_blk = M.G > 0 ? (int)std::min<long long>(((M.G + 1) / 2 + 255) / 256, 64) : 0;
 #ifndef BB_EMU
         if (need > 64 * 1024) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)k_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-            hipError_t e2 = hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipError_t e1 = hipFuncSetAttribute((const void*)sample_kernel(M.kind), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipError_t e2 = hipFuncSetAttribute((const void*)update_kernel(M.kind), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
             if (e1 != hipSuccess || e2 != hipSuccess) { bb_destroy(h); return bb_fail(BB_ERR_DEVICE, "cannot raise dynamic LDS to %zu bytes", need); }
         }
 #endif
@@ -489,16 +499,16 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     const size_t D = (size_t)M.D;
     BB_TRY(dalloc(h, &S.mu, D + 2));
     BB_TRY(dalloc(h, &S.om, D + 2));
-    BB_TRY(dalloc(h, &S.eps, D + 2));
-    BB_TRY(dalloc(h, &S.sp, D + 2));
-    BB_TRY(dalloc(h, &S.sig, D + 2));
+    BB_TRY(dalloc(h, &S.zsv, D + 2));
+    BB_TRY(dalloc(h, &S.asv, D + 2));
+    BB_TRY(dalloc(h, &S.hsv, D + 2));
     BB_TRY(dalloc(h, &S.acc_mu, D + 2));
     BB_TRY(dalloc(h, &S.acc_om, D + 2));
     BB_TRY(dalloc(h, &S.gacc_mu, D + 2));
     BB_TRY(dalloc(h, &S.gacc_om, D + 2));
     BB_TRY(dalloc(h, &h->bak_mu, D + 2));
     BB_TRY(dalloc(h, &h->bak_om, D + 2));
-    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * D));
+    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dp));
     BB_TRY(dalloc(h, &S.partials, (size_t)M.K * (size_t)h->nblk));
     BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
     BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
@@ -509,6 +519,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &S.elbo_ring, (size_t)BB_ELBO_RING));
     BB_TRY(dalloc(h, &S.elbo_sample, (size_t)opts->samples_per_step + 64));
     BB_TRY(dalloc(h, &S.ctr, (size_t)2));
+    BB_TRY(dalloc(h, &S.stamps, (size_t)h->nblk * 32));
     S.eps_in = nullptr;
 
     // algorithmic bytes per step on this shard: theta r+w, optimiser state r+w, counts
@@ -598,17 +609,31 @@ static int launch_check() {
 
 static int launch_sample(bb_handle* h, const RunArgs& A) {
 #ifdef BB_EMU
-    emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) { bb_block_sample(cx, h->M, h->S, A, h->NB); });
+    emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) {
+        switch (h->M.kind) {
+        case 0: bb_block_sample<0>(cx, h->M, h->S, A, h->NB); break;
+        case 1: bb_block_sample<1>(cx, h->M, h->S, A, h->NB); break;
+        case 2: bb_block_sample<2>(cx, h->M, h->S, A, h->NB); break;
+        default: bb_block_sample<3>(cx, h->M, h->S, A, h->NB);
+        }
+    });
 #else
-    hipLaunchKernelGGL(k_sample, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
+    hipLaunchKernelGGL(sample_kernel(h->M.kind), dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
 #endif
     return LAUNCH_CHECK();
 }
 static int launch_update(bb_handle* h, const RunArgs& A) {
 #ifdef BB_EMU
-    emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) { bb_block_update(cx, h->M, h->S, A, h->NB); });
+    emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) {
+        switch (h->M.kind) {
+        case 0: bb_block_update<0>(cx, h->M, h->S, A, h->NB); break;
+        case 1: bb_block_update<1>(cx, h->M, h->S, A, h->NB); break;
+        case 2: bb_block_update<2>(cx, h->M, h->S, A, h->NB); break;
+        default: bb_block_update<3>(cx, h->M, h->S, A, h->NB);
+        }
+    });
 #else
-    hipLaunchKernelGGL(k_update, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
+    hipLaunchKernelGGL(update_kernel(h->M.kind), dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
 #endif
     return LAUNCH_CHECK();
 }
@@ -698,7 +723,7 @@ static int reset_optimizer(bb_handle* h) {
     const size_t D = (size_t)h->M.D;
     int rc;
     if (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD) {
-        if ((rc = dzero(h->S.hist, (size_t)h->o.window * 2 * D * 8, h->stream))) return rc;
+        if ((rc = dzero(h->S.hist, (size_t)h->o.window * 2 * (size_t)h->M.Dp * 8, h->stream))) return rc;
         if ((rc = dzero(h->S.acc_mu, D * 8, h->stream))) return rc;
         if ((rc = dzero(h->S.acc_om, D * 8, h->stream))) return rc;
     } else {
@@ -948,6 +973,14 @@ extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int
     if ((rc = launch_check())) return rc;
 #endif
     return d2h(out, h->dbg_buf, n * 8, h->stream);
+}
+
+extern "C" int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n) {
+    if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    const int64_t have = (int64_t)h->nblk * 32;
+    int rc = dsync(h->stream);
+    if (rc) return rc;
+    return d2h(out, h->S.stamps, (size_t)std::min(n, have) * 8, h->stream);
 }
 
 extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {

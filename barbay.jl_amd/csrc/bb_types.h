@@ -28,6 +28,7 @@ struct DevPrior {
 struct DevModel {
     int kind, R, E, G;
     long long nn, nb, B, D;
+    long long Dp;                     // D rounded up to a multiple of 8: stride of the optimiser-history slots (16-B aligned pairs)
     int T[BB_MAX_REP];
     unsigned Tmagic[BB_MAX_REP];      // floor(2^32 / T) + 1: n / T == umulhi(n, magic) for n < 2^16
     unsigned Tmagic1[BB_MAX_REP];     // same for T - 1
@@ -48,9 +49,9 @@ struct DevModel {
 
 struct DevState {
     double *mu, *om;                  // [D] variational parameters theta = [mu; omega]
-    double *eps, *sp, *sig;           // [D] per-sample scratch: draw, softplus(omega), sigmoid(omega)
+    double *zsv, *asv, *hsv;          // [D] per-sample scratch: z, eps*sigmoid(omega) (= dz/domega), sigmoid/softplus (= dH/domega)
     double *acc_mu, *acc_om;          // [D] optimiser accumulators
-    double *hist;                     // [W][2][D] TruncatedADAGrad window of squared gradients
+    double *hist;                     // [W][2][Dp] TruncatedADAGrad window of squared gradients
     double *gacc_mu, *gacc_om;        // [D] S > 1 accumulation / gradient export
     double *partials;                 // [K][nblk]
     double *totals;                   // [K]
@@ -63,6 +64,7 @@ struct DevState {
     double *elbo_sample;              // [S]
     unsigned long long *ctr;          // [2] device-side step counter (ping-pong)
     const double *eps_in;             // [S][D] caller-supplied draws (test hook) or nullptr
+    unsigned long long *stamps;       // [nblk][32] s_memtime stamps (diagnostic build -DBB_STAMPS only)
 };
 
 #define BB_ELBO_RING 4096

@@ -163,6 +163,10 @@ int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out);
 /* The engine's normal stream for (step, stream) over latents [lo, hi), for checks. */
 int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, int64_t hi, double* out);
 
+/* s_memtime stamps at the pass boundaries of the last launches, [n_blocks][32]; all zero unless
+ * the library was built with -DBB_STAMPS (diagnostic build, never the shipped one). */
+int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n);
+
 int bb_get_stats(bb_handle* h, bb_stats* out);
 
 /* ---- sharded execution -------------------------------------------------------------

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a step's cycles go.  Builds barbay.jl_amd/lib/libbarbay_hip_stamps.so with
+-DBB_STAMPS (s_memtime at every pass boundary), runs the C2 workload a few steps and prints the
+median per-pass cycle shares over workgroups.  Read SHARES, not lengths (the stamps perturb)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+out = os.path.join(g.PKG, "lib", "libbarbay_hip_stamps.so")
+if "--build-only" in sys.argv or not os.path.exists(out):
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-DBB_STAMPS", "-fPIC", "-shared",
+                    "-Wl,-Bsymbolic", g.SRC, "-o", out, "-ldl"], check=True)
+    if "--build-only" in sys.argv:
+        sys.exit(0)
+import barbay_jl_amd as bb  # noqa: E402
+from barbay_jl_amd import _capi, synth  # noqa: E402
+
+lib = _capi.load_library(out)
+wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42)
+e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, steps_per_graph=-1, _lib=lib)
+e.run(21)
+st = e.stamps().astype(np.int64)
+names = {1: "S draw", 2: "E tables", 3: "M accumulate", 4: "M reduce", 5: "row_sum", 6: "write partials",
+         9: "F sum rows", 10: "F finish", 11: "stage z", 12: "E tables", 13: "R residuals", 14: "U unit sums",
+         15: "G gather+update", 16: "tail"}
+print(e.stats())
+for lo, hi, title in ((0, 6, "k_sample"), (8, 16, "k_update")):
+    tot = np.median(st[:, hi] - st[:, lo])
+    print(f"{title}: median block span {tot:.0f} cycles (s_memtime ticks)")
+    prev = lo
+    for i in range(lo + 1, hi + 1):
+        if i not in names or not st[:, i].any():
+            continue
+        d = np.median(st[:, i] - st[:, prev])
+        print(f"   {names[i]:16s} {d:9.0f}  {100 * d / tot:5.1f}%")
+        prev = i
+    print(f"   first block start -> last block end: {st[:, hi].max() - st[:, lo].min()} ticks")
