@@ -1,0 +1,113 @@
+"""`BarBay.vi.advi` with the reference's keyword surface (src/vi.jl:86-101), the HIP engine in place of
+`q = Turing.vi(bayes_model, advi; optimizer=opt)` (src/vi.jl:201).
+
+Differences from the reference, all additive: `advi` / `opt` are the small dataclasses below instead of
+Turing types (`ADVI(samples_per_step, max_iters)`, `TruncatedADAGrad(eta, tau, n)`,
+`DecayedADAGrad(eta, pre, post)`, src/vi.jl:98-99), and `seed`, `device`, `engine_kwargs` select the
+Philox key, the GPU and engine options.  Errors the reference raises with `error(...)` are `BarBayError`.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Callable, Dict, Optional, Union
+
+import numpy as np
+
+from . import utils
+from ._capi import Engine
+from .model import BarBayError, BayesModel
+
+log = logging.getLogger("barbay")
+
+
+@dataclass
+class ADVI:
+    """Turing.ADVI(samples_per_step, max_iters) (src/vi.jl:98; default (1, 10_000))."""
+    samples_per_step: int = 1
+    max_iters: int = 10_000
+
+
+@dataclass
+class TruncatedADAGrad:
+    """AdvancedVI.TruncatedADAGrad(eta=0.1, tau=40, n=100) (src/vi.jl:99)."""
+    eta: float = 0.1
+    tau: float = 40.0
+    n: int = 100
+
+
+@dataclass
+class DecayedADAGrad:
+    """AdvancedVI.DecayedADAGrad(eta=0.1, pre=1.0, post=0.9) (src/vi.jl:75)."""
+    eta: float = 0.1
+    pre: float = 1.0
+    post: float = 0.9
+
+
+def make_engine(bayes_model: BayesModel, advi: ADVI, opt, seed: int = 0, device: int = 0, **engine_kwargs) -> Engine:
+    pri = {k: (m if m.shape[0] > 1 else float(m[0]), s if s.shape[0] > 1 else float(s[0]))
+           for k, (m, s) in bayes_model.priors.items()}
+    if isinstance(opt, TruncatedADAGrad):
+        okw = dict(optimizer="TruncatedADAGrad", eta=opt.eta, tau=opt.tau, window=opt.n)
+    elif isinstance(opt, DecayedADAGrad):
+        okw = dict(optimizer="DecayedADAGrad", eta=opt.eta, pre=opt.pre, post=opt.post)
+    else:
+        raise BarBayError("opt must be TruncatedADAGrad or DecayedADAGrad")
+    return Engine(bayes_model.kind, bayes_model.counts, bayes_model.n_neutral, bayes_model.n_bc,
+                  totals=bayes_model.totals, env_idx=bayes_model.env_idx, geno_idx=bayes_model.geno_idx, priors=pri,
+                  samples_per_step=advi.samples_per_step, seed=seed, device=device, **okw, **engine_kwargs)
+
+
+def vi(bayes_model: BayesModel, advi: ADVI, optimizer=None, seed: int = 0, device: int = 0, **engine_kwargs):
+    """`Turing.vi(model, advi; optimizer)`: returns q with q.dist.m, q.dist.σ, q.transform.ranges_out --
+    the fields `utils.advi_to_df` reads (src/utils.jl:1049, 1060)."""
+    with make_engine(bayes_model, advi, optimizer or TruncatedADAGrad(), seed, device, **engine_kwargs) as e:
+        e.run(advi.max_iters)
+        m, s = e.posterior()
+        ranges = [(lo, hi) for _, lo, hi in e.layout()]
+    dist = SimpleNamespace(m=m, σ=s, sigma=s)
+    return SimpleNamespace(dist=dist, transform=SimpleNamespace(ranges_out=ranges))
+
+
+def advi(*, data, outputname: Optional[str] = None, model: Callable, model_kwargs: Optional[Dict] = None,
+         id_col="barcode", time_col="time", count_col="count", neutral_col="neutral", rep_col: Optional[str] = None,
+         env_col: Optional[str] = None, genotype_col: Optional[str] = None, advi: Optional[ADVI] = None,
+         opt: Union[TruncatedADAGrad, DecayedADAGrad, None] = None, verbose: bool = True, seed: int = 0, device: int = 0,
+         engine_kwargs: Optional[Dict] = None):
+    """src/vi.jl:86-235."""
+    advi = advi or ADVI()
+    opt = opt or TruncatedADAGrad()
+    model_kwargs = dict(model_kwargs or {})
+    fname = None if outputname is None else f"{outputname}.csv"                    # :103
+    if fname is not None and os.path.isfile(fname):                                # :106-108
+        raise BarBayError(f"{fname} was already processed")
+    mname = getattr(model, "__name__", str(model))
+    if "replicate" in mname and rep_col is None:                                   # :111-113
+        raise BarBayError("Hierarchical models for experimental replicates require argument `:rep_col`")
+    if "multienv" in mname and env_col is None:                                    # :116-118
+        raise BarBayError("Models with multiple environments require argument `:env_col`")
+    if verbose:
+        log.info("Pre-processing data...")                                         # :122-124
+    cols = dict(id_col=id_col, time_col=time_col, count_col=count_col, neutral_col=neutral_col, rep_col=rep_col,
+                env_col=env_col, genotype_col=genotype_col)
+    arrays = utils.data_to_arrays(data, **cols)                                    # :127-136
+    if verbose:
+        log.info("Initialize Variational Inference Optimization...")               # :140-142
+    if "multienv" in mname:                                                        # :146-156
+        model_kwargs = {"envs": arrays.envs, **model_kwargs}
+    if "genotype" in mname:                                                        # :159-169
+        model_kwargs = {"genotypes": arrays.genotypes, **model_kwargs}
+    bayes_model = model(arrays.bc_count, arrays.bc_total, arrays.n_neutral, arrays.n_bc, **model_kwargs)   # :172-178
+    if not isinstance(bayes_model, BayesModel):
+        raise BarBayError("model must be one of barbay model constructors (BarBay.model.*)")
+    q = vi(bayes_model, advi, opt, seed, device, **(engine_kwargs or {}))          # :201
+    var_names = []                                                                 # :184-198
+    for sym, (lo, hi) in zip(bayes_model.var_symbols(), q.transform.ranges_out):
+        var_names += [f"{sym}[{x}]" for x in range(1, hi - lo + 1)]
+    df = utils.advi_to_df(data, q, var_names, **cols, rng=np.random.default_rng(seed))   # :203-215
+    if fname is None:
+        return df
+    df.to_csv(fname, index=False)                                                  # :218-233
+    return None
