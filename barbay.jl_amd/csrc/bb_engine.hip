@@ -192,7 +192,8 @@ struct bb_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bb_ncclComm_t comm = nullptr;
 #endif
-    bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE; }
+    bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
+    bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
 };
 
 template <class T>
@@ -293,6 +294,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
 
     bb_handle* h = new bb_handle();
     h->o = *opts;
+    { const char* fr = getenv("BB_FORCE_ALLREDUCE"); h->force_reduce = fr && atoi(fr) > 0; }
     if (h->o.resum_every <= 0) h->o.resum_every = h->o.window > 0 ? h->o.window : 1;
     DevModel& M = h->M;
     M.kind = md->kind;
@@ -664,7 +666,7 @@ static int launch_geno_sum(bb_handle* h) {
 }
 
 static int allreduce(bb_handle* h, double* buf, size_t n) {
-    if (h->o.world_size == 1) return 0;
+    if (h->o.world_size == 1 && !h->force_reduce) return 0;
 #ifdef BB_EMU
     (void)buf; (void)n;
     return bb_fail(BB_ERR_COMM, "in-library collectives are not available in the emulation build");
@@ -810,7 +812,7 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
     // pattern must repeat with the graph -> only when ELBO recording is off; no collectives inside.
     int gs = h->o.steps_per_graph == 0 ? 50 : h->o.steps_per_graph;
-    const bool graph_ok = gs > 0 && h->o.world_size == 1 && h->o.elbo_every == 0;
+    const bool graph_ok = gs > 0 && h->o.world_size == 1 && !h->force_reduce && h->o.elbo_every == 0;
     if (graph_ok) {
         gs &= ~1;
         if (gs < 2) gs = 2;

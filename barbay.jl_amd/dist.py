@@ -1,0 +1,51 @@
+"""One-process-per-GPU driving of a sharded engine with `torch.distributed` as the plumbing.
+
+* `init_rccl(engine)`       -- in-library RCCL: rank 0 makes the id, it is broadcast, every rank joins;
+                               `engine.run(n)` then issues one ncclAllReduce of K doubles per MC sample.
+* `run_external(engine, n)` -- the same step with the reduction done by `torch.distributed.all_reduce`
+                               on the host buffer (any backend; this is what the gloo tests drive).
+* `gather_posterior(...)`   -- full (mean, sigma) on every rank from the per-rank shards.
+"""
+from __future__ import annotations
+
+from typing import Dict, Sequence, Tuple
+
+import numpy as np
+
+from .sharding import owned_indices
+
+
+def init_rccl(engine) -> None:
+    import torch.distributed as dist
+    ids = [engine.make_comm_id() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    engine.comm_init(ids[0])
+
+
+def run_external(engine, n_steps: int) -> None:
+    import torch
+    import torch.distributed as dist
+    for _ in range(n_steps * engine.samples_per_step):
+        t = torch.from_numpy(engine.step_moments())
+        if dist.get_backend() == "nccl":
+            g = t.cuda()
+            dist.all_reduce(g)
+            t = g.cpu()
+        else:
+            dist.all_reduce(t)
+        engine.step_apply(t.numpy())
+
+
+def gather_posterior(engine, kind: str, n_neutral: int, n_bc: int, n_time: Sequence[int], n_rep: int = 1,
+                     n_env: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    import torch.distributed as dist
+    mean, sigma = engine.posterior()
+    st = engine.stats()
+    layout: Dict[str, Tuple[int, int]] = {n: (lo, hi) for n, lo, hi in engine.layout()}
+    ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, (ix, mean[ix], sigma[ix]))
+    for i, m, s in parts:
+        mean[i] = m
+        sigma[i] = s
+    return mean, sigma

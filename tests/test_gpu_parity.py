@@ -93,3 +93,19 @@ def test_full_size_properties(hip_lib):
         assert np.all(np.isfinite(tr)) and tr[-1] > tr[0]
         m, s = e.posterior()
         assert np.isfinite(m).all() and (s > 0).all()
+
+
+def test_rccl_path_single_rank(hip_lib, monkeypatch):
+    """The in-library collective path (k_reduce -> ncclAllReduce on the engine's stream -> k_update) with a
+    one-rank communicator equals the collective-free path (same moments, different summation grouping)."""
+    from conftest import make_engine
+    sp = c.synth("fitness_multi_tile", seed=8)
+    with make_engine(sp, hip_lib, seed=3) as e:
+        e.run(25)
+        ref = e.get_params()
+    monkeypatch.setenv("BB_FORCE_ALLREDUCE", "1")
+    with make_engine(sp, hip_lib, seed=3) as e:
+        e.comm_init(e.make_comm_id())
+        e.run(25)
+        got = e.get_params()
+    assert np.abs(got[0] - ref[0]).max() < 1e-9 and np.abs(got[1] - ref[1]).max() < 1e-9
