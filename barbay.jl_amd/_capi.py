@@ -49,7 +49,7 @@ class bb_advi_opts(C.Structure):
         ("samples_per_step", C.c_int32), ("optimizer", C.c_int32), ("eta", C.c_double), ("tau", C.c_double),
         ("window", C.c_int32), ("resum_every", C.c_int32), ("pre", C.c_double), ("post", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("steps_per_graph", C.c_int32), ("elbo_every", C.c_int32),
+        ("steps_per_graph", C.c_int32), ("elbo_every", C.c_int32), ("launch_mode", C.c_int32),
     ]
 
 
@@ -146,7 +146,7 @@ class Engine:
                  samples_per_step: int = 1, optimizer: str = "TruncatedADAGrad", eta: float = 0.1,
                  tau: float = 40.0, window: int = 100, resum_every: int = 0, pre: float = 1.0,
                  post: float = 0.9, seed: int = 0, device: int = 0, rank: int = 0, world_size: int = 1,
-                 steps_per_graph: int = 0, elbo_every: int = 0, _lib: Optional[C.CDLL] = None):
+                 steps_per_graph: int = 0, elbo_every: int = 0, launch_mode: int = 0, _lib: Optional[C.CDLL] = None):
         self._lib = _lib if _lib is not None else load_library()
         self._h = C.c_void_p()
         self.kind = kind
@@ -193,7 +193,7 @@ class Engine:
         o.optimizer = {"TruncatedADAGrad": 0, "DecayedADAGrad": 1}[optimizer]
         o.eta, o.tau, o.window, o.resum_every, o.pre, o.post = eta, tau, window, resum_every, pre, post
         o.seed, o.device, o.rank, o.world_size = seed, device, rank, world_size
-        o.steps_per_graph, o.elbo_every = steps_per_graph, elbo_every
+        o.steps_per_graph, o.elbo_every, o.launch_mode = steps_per_graph, elbo_every, launch_mode
         self._check(self._lib.bb_create(C.byref(md), C.byref(o), C.byref(self._h)))
         self.D = int(self._lib.bb_num_latents(self._h))
         self.samples_per_step = samples_per_step

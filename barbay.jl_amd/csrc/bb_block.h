@@ -45,6 +45,12 @@ BB_DEV void bb_sincospi(double x, double* s, double* c) { sincospi(x, s, c); }
 #else
 #define BB_STAMP(cx, S, i) ((void)0)
 #endif
+// wave-0 timeline stamp after draining this wave's outstanding memory operations
+#if defined(BB_STAMPS) && !defined(BB_EMU)
+#define BB_STAMP_W(cx, S, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) (S).stamps[(long long)(cx).block * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BB_STAMP_W(cx, S, i) ((void)0)
+#endif
 
 #include "bb_math.h"
 
@@ -53,6 +59,21 @@ BB_DEV void bb_sincospi(double x, double* s, double* c) { sincospi(x, s, c); }
 #define BB_LOG2PI 1.8378770664093454835606594728112
 
 struct alignas(16) bb_d2 { double x, y; };
+
+// Loads / stores of words another workgroup of the SAME launch writes / reads (persistent kernel):
+// agent-scope relaxed atomics = global_load/store ... sc1 (write-through, L1-bypassing); plain otherwise.
+template <bool COH> BB_DEV double bb_ld(const double* p) {
+#if !defined(BB_EMU)
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return *p;
+}
+template <bool COH> BB_DEV void bb_st(double* p, double v) {
+#if !defined(BB_EMU)
+    if (COH) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+#endif
+    *p = v;
+}
 #define BB_MAX_SEG (4 + 4 * BB_MAX_REP)
 
 // ------------------------------------------------------------------------------------------------
@@ -103,7 +124,7 @@ BB_DEV void bb_prior_of(const DevModel& M, int blk, long long j, double* mean, d
 // LDS carve-up (offsets in doubles) for a tile of NB barcodes worked by nthr threads.
 // ------------------------------------------------------------------------------------------------
 struct BBLds {
-    int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg;
+    int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg, zgl;
     int total;
 };
 
@@ -141,6 +162,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.Dt = o;   o += Ttot;
     L.elbt = o; o += Ttot;
     L.seg = o;  o += 5 * (BB_MAX_SEG + 1);
+    L.zgl = o;  o += 2 * nt1;
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -282,19 +304,27 @@ BB_DEV double bb_sample_pair(const DevModel& M, const DevState& S, const RunArgs
     return el;
 }
 
+// Where a step lands in the TruncatedADAGrad window: computed ONCE per sweep (64-bit modulo on the CU's one
+// scalar unit is expensive when every wave repeats it per parameter).
+struct BBSlot { int slot; bool resum; };
+BB_DEV BBSlot bb_slot_of(const RunArgs& A, unsigned long long step) {
+    BBSlot w;
+    w.slot = A.opt == 0 ? (int)(step % (unsigned long long)A.W) : 0;
+    w.resum = A.opt == 0 && (A.resum_every == 1 || (step > 0 && step % (unsigned long long)A.resum_every == 0));
+    return w;
+}
+
 // One optimiser update of parameter *p with gradient-of-(-ELBO) d.  which: 0 = mu, 1 = omega.
-BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A, unsigned long long step,
+BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot w,
                          int which, long long i, double d, double old_slot, double* new_slot, double* p, double* acc) {
     double upd;
     if (A.opt == 0) {   // TruncatedADAGrad: g2[mod(i-1,n)+1] = d^2; s = sum(g2); d *= eta / (tau + sqrt(s))
-        const int slot = (int)(step % (unsigned long long)A.W);
         const double n2 = d * d;
         *new_slot = n2;
         double s;
-        const bool resum = A.resum_every == 1 || (step > 0 && step % (unsigned long long)A.resum_every == 0);
-        if (resum) {
+        if (w.resum) {
             s = 0.0;
-            for (int j = 0; j < A.W; ++j) s += (j == slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
+            for (int j = 0; j < A.W; ++j) s += (j == w.slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
         } else {
             s = fmax(*acc + n2 - old_slot, 0.0);
         }
@@ -310,7 +340,7 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
 
 // Finish one pair given the likelihood part of d logjoint / d z for its two latents: prior term,
 // reparameterisation gradient w.r.t. (mu, omega), S-sample averaging, entropy term, optimiser.
-BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& A, unsigned long long step, int blk,
+BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot w, int blk,
                            long long i0, bool a0, bool a1, double z0, double z1, double gl0, double gl1) {
     const long long i1 = i0 + 1, blo = M.blk_lo[blk];
     const bool both = a0 && a1;
@@ -345,9 +375,8 @@ BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& 
     double* hs_m = nullptr;
     double* hs_o = nullptr;
     if (A.opt == 0) {
-        const int slot = (int)(step % (unsigned long long)A.W);
-        hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dp;
-        hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
+        hs_m = S.hist + ((long long)w.slot * 2 + 0) * M.Dp;
+        hs_o = S.hist + ((long long)w.slot * 2 + 1) * M.Dp;
     }
     if (both) {
         mu = *(const bb_d2*)(S.mu + i0); om = *(const bb_d2*)(S.om + i0);
@@ -363,12 +392,12 @@ BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& 
     }
     bb_d2 nhm = hm, nho = ho;
     if (a0) {
-        bb_opt_apply(M, S, A, step, 0, i0, -gm[0], hm.x, &nhm.x, &mu.x, &am.x);
-        bb_opt_apply(M, S, A, step, 1, i0, -go[0], ho.x, &nho.x, &om.x, &ao.x);
+        bb_opt_apply(M, S, A, w, 0, i0, -gm[0], hm.x, &nhm.x, &mu.x, &am.x);
+        bb_opt_apply(M, S, A, w, 1, i0, -go[0], ho.x, &nho.x, &om.x, &ao.x);
     }
     if (a1) {
-        bb_opt_apply(M, S, A, step, 0, i1, -gm[1], hm.y, &nhm.y, &mu.y, &am.y);
-        bb_opt_apply(M, S, A, step, 1, i1, -go[1], ho.y, &nho.y, &om.y, &ao.y);
+        bb_opt_apply(M, S, A, w, 0, i1, -gm[1], hm.y, &nhm.y, &mu.y, &am.y);
+        bb_opt_apply(M, S, A, w, 1, i1, -go[1], ho.y, &nho.y, &om.y, &ao.y);
     }
     if (both) {
         *(bb_d2*)(S.mu + i0) = mu; *(bb_d2*)(S.om + i0) = om;
@@ -444,57 +473,12 @@ BB_DEV double bb_effective_tables(BBCtx& cx, int tid, const DevModel& M, const D
     return el;
 }
 
-// ================================================================================================
-// block_sample: sampling sweep + partial moments of one tile
-// ================================================================================================
+// pass M: per replicate, every (barcode, time) element contributes to the moments of its time; the
+// tile's column sums land in lds[L.wk + row].  `we` also accumulates the Poisson ELBO terms.
 template <int KIND>
-BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+BB_DEV void bb_pass_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, const BBTile& t, int NB, bool we) {
     double* lds = cx.lds;
-    const BBTile t = bb_tile(M, A, cx.block, NB);
-    const unsigned step = (unsigned)S.ctr[A.par];
     const int X = bb_xdim<KIND>(M);
-    const bool we = A.with_elbo != 0;
-
-    BB_STAMP(cx, S, 0);
-    BBSeg* sg = (BBSeg*)(lds + L.seg);
-    int* li = (int*)(lds + L.misc);
-    BB_PASS(cx, tid) {
-        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
-        for (int k = tid; k < M.K; k += cx.nthr) lds[L.wk + k] = 0.0;
-    }
-    BB_SYNC(cx);
-    // pass S: draw every latent of the tile (block 0 also draws the replicated global latents)
-    BB_PASS(cx, tid) {
-        double el = 0.0;
-        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
-            double z0, z1;
-            const double e = bb_sample_pair(M, S, A, step, s.blk, i0, a0, a1, we, &z0, &z1);
-            if (s.kind >= SK_GS) {
-                double* zg = S.zg + (s.kind == SK_GLS ? M.nt1 : 0);
-                if (a0) zg[i0 - s.lo] = z0;
-                if (a1) zg[i0 + 1 - s.lo] = z1;
-                if (A.count_globals) el += e;
-            } else {
-                if (a0) lds[s.ldsoff + (i0 - s.lo)] = z0;
-                if (a1) lds[s.ldsoff + (i0 + 1 - s.lo)] = z1;
-                el += e;
-            }
-        });
-        lds[L.acc + BB_NQ * cx.nthr + tid] = el;
-    }
-    BB_SYNC(cx);
-    BB_STAMP(cx, S, 1);
-
-    // pass E: effective fitness / precision per unit
-    BB_PASS(cx, tid) {
-        double el = bb_effective_tables<KIND>(cx, tid, M, S, L, t, we);
-        lds[L.acc + BB_NQ * cx.nthr + tid] += el;
-    }
-    BB_SYNC(cx);
-    BB_STAMP(cx, S, 2);
-
-    // pass M: per replicate, every (barcode, time) element contributes to the moments of its time
     for (int r = 0; r < M.R; ++r) {
         const int T = M.T[r];
         const int bstride = cx.nthr / T, nact = bstride * T;
@@ -557,6 +541,59 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
         }
         BB_SYNC(cx);
     }
+}
+
+// ================================================================================================
+// block_sample: sampling sweep + partial moments of one tile
+// ================================================================================================
+template <int KIND>
+BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    double* lds = cx.lds;
+    const BBTile t = bb_tile(M, A, cx.block, NB);
+    const unsigned step = (unsigned)S.ctr[A.par];
+    const int X = bb_xdim<KIND>(M);
+    const bool we = A.with_elbo != 0;
+
+    BB_STAMP(cx, S, 0);
+    BBSeg* sg = (BBSeg*)(lds + L.seg);
+    int* li = (int*)(lds + L.misc);
+    BB_PASS(cx, tid) {
+        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
+        for (int k = tid; k < M.K; k += cx.nthr) lds[L.wk + k] = 0.0;
+    }
+    BB_SYNC(cx);
+    // pass S: draw every latent of the tile (block 0 also draws the replicated global latents)
+    BB_PASS(cx, tid) {
+        double el = 0.0;
+        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
+            double z0, z1;
+            const double e = bb_sample_pair(M, S, A, step, s.blk, i0, a0, a1, we, &z0, &z1);
+            if (s.kind >= SK_GS) {
+                double* zg = S.zg + (s.kind == SK_GLS ? M.nt1 : 0);
+                if (a0) zg[i0 - s.lo] = z0;
+                if (a1) zg[i0 + 1 - s.lo] = z1;
+                if (A.count_globals) el += e;
+            } else {
+                if (a0) lds[s.ldsoff + (i0 - s.lo)] = z0;
+                if (a1) lds[s.ldsoff + (i0 + 1 - s.lo)] = z1;
+                el += e;
+            }
+        });
+        lds[L.acc + BB_NQ * cx.nthr + tid] = el;
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 1);
+
+    // pass E: effective fitness / precision per unit
+    BB_PASS(cx, tid) {
+        double el = bb_effective_tables<KIND>(cx, tid, M, S, L, t, we);
+        lds[L.acc + BB_NQ * cx.nthr + tid] += el;
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 2);
+
+    bb_pass_moments<KIND>(cx, M, S, L, t, NB, we);
     BB_STAMP(cx, S, 4);
     if (we) bb_row_sum(cx, lds + L.acc + BB_NQ * cx.nthr, cx.nthr, lds + L.part, lds + L.wk + (M.K - 2));
     BB_STAMP(cx, S, 5);
@@ -568,10 +605,12 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
 }
 
 // Sum the moment rows and finish everything that depends on them (per replicate, tiny).
-BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L) {
+template <bool COH>
+BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, const double* zg) {
     double* lds = cx.lds;
-    // two-level, fixed-order sum of each moment row: 16 strided partial sums, then one add chain
-    if (A.nred > 1) {
+    // fixed-order sum of each moment row; the sampled global latents come along into LDS (gglob is free until
+    // the finish writes the global gradients there)
+    if (A.nred > 16) {   // two-level: 16 strided partial sums, then one add chain
         double* tmp = lds + L.red;
         BB_PASS(cx, tid) {
             for (int w = tid; w < M.K * 16; w += cx.nthr) {
@@ -581,11 +620,12 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 for (int j0 = c; j0 < A.nred; j0 += 128) {   // 8 independent loads in flight, fixed add tree
                     double v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (j0 + 16 * i < A.nred) ? row[j0 + 16 * i] : 0.0;
+                    for (int i = 0; i < 8; ++i) v[i] = (j0 + 16 * i < A.nred) ? bb_ld<COH>(row + j0 + 16 * i) : 0.0;
                     s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 }
                 tmp[w] = s;
             }
+            for (int j = tid; j < 2 * M.nt1; j += cx.nthr) lds[L.zgl + j] = bb_ld<COH>(zg + j);
         }
         BB_SYNC(cx);
         BB_PASS(cx, tid) {
@@ -595,9 +635,18 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 lds[L.wk + k] = s;
             }
         }
-    } else {
+    } else {             // few rows (totals, or the 8 group rows of the persistent launch): one batch per thread
         BB_PASS(cx, tid) {
-            for (int k = tid; k < M.K; k += cx.nthr) lds[L.wk + k] = A.red[k];
+            for (int k = tid; k < M.K; k += cx.nthr) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = i < A.nred ? bb_ld<COH>(A.red + (long long)k * A.nred + i) : 0.0;
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += v[i];
+                lds[L.wk + k] = s;
+            }
+            for (int j = tid; j < 2 * M.nt1; j += cx.nthr) lds[L.zgl + j] = bb_ld<COH>(zg + j);
         }
     }
     BB_SYNC(cx);
@@ -624,7 +673,7 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 const double nn = (double)M.nn;
                 const double* mm = lds + L.wk + M.kq[r] + T + 5 * tt;
                 const double M0 = mm[0], M1 = mm[1], M2 = mm[2], N1 = mm[3], N2 = mm[4];
-                const double sbar = S.zg[M.off_t[r] + tt], ls = S.zg[M.nt1 + M.off_t[r] + tt];
+                const double sbar = lds[L.zgl + M.off_t[r] + tt], ls = lds[L.zgl + M.nt1 + M.off_t[r] + tt];
                 const double wb = bb_exp(-2.0 * ls);
                 const double c = lds[L.Lt + j + 1] - lds[L.Lt + j] - sbar;
                 const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
@@ -657,46 +706,12 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
     BB_SYNC(cx);
 }
 
-// ================================================================================================
-// block_update: gradient of the log-joint for the tile's latents + optimiser step
-// ================================================================================================
+// passes R + U: residuals r = (l[t+1] - l[t]) - s_eff - c_t of every (barcode, time step), then the per-unit
+// sums As = sum_t w r (= dlogp/ds_eff) and Qs = sum_t (w r^2 - 1) (= dlogp/dlogsigma_eff).
 template <int KIND>
-BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, const BBTile& t, int NB) {
     double* lds = cx.lds;
-    const BBTile t = bb_tile(M, A, cx.block, NB);
-    const unsigned long long step = S.ctr[A.par];
     const int X = bb_xdim<KIND>(M);
-
-    BB_STAMP(cx, S, 8);
-    bb_finalize(cx, M, S, A, L);
-    BB_STAMP(cx, S, 10);
-
-    BBSeg* sg = (BBSeg*)(lds + L.seg);
-    int* li = (int*)(lds + L.misc);
-    BB_PASS(cx, tid) {
-        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
-    }
-    BB_SYNC(cx);
-    // stage: the saved draw of every tile latent back into LDS
-    BB_PASS(cx, tid) {
-        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
-            if (s.kind >= SK_GS) return;
-            if (a0 && a1) {
-                const bb_d2 z = *(const bb_d2*)(S.zsv + i0);
-                lds[s.ldsoff + (i0 - s.lo)] = z.x;
-                lds[s.ldsoff + (i0 + 1 - s.lo)] = z.y;
-            } else if (a0) lds[s.ldsoff + (i0 - s.lo)] = S.zsv[i0];
-            else lds[s.ldsoff + (i0 + 1 - s.lo)] = S.zsv[i0 + 1];
-        });
-    }
-    BB_SYNC(cx);
-    BB_STAMP(cx, S, 11);
-    BB_PASS(cx, tid) { bb_effective_tables<KIND>(cx, tid, M, S, L, t, false); }
-    BB_SYNC(cx);
-    BB_STAMP(cx, S, 12);
-
-    // pass R: residuals r = (l[t+1] - l[t]) - s_eff - c_t of every (barcode, time step)
     for (int r = 0; r < M.R; ++r) {
         const int T = M.T[r], T1 = T - 1, tc = M.tcum[r];
         const double* zl = lds + L.zl + NB * tc;
@@ -739,46 +754,95 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
     BB_SYNC(cx);
     BB_STAMP(cx, S, 14);
 
+}
+
+// Likelihood part of d logjoint / d z for latent j of segment s (z = its sample), gathered from the LDS tables.
+template <int KIND>
+BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, const BBTile& t, int NB, const BBSeg& s,
+                      long long j, double z) {
+    const int ns = t.nshift;
+    const int X = bb_xdim<KIND>(M);
+    switch (s.kind) {
+    case SK_L: {
+        const int r = s.r, T = M.T[r], T1 = T - 1, tc = M.tcum[r];
+        const double* res = lds + L.res + NB * (tc - r);
+        const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
+        const bool mut = bl >= ns;
+        const double lam = bb_exp(z);
+        const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
+        double g = cnt - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
+        if (tt < T1) {
+            const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)] : lds[L.wbar + tc + tt];
+            g += w * res[bl * T1 + tt];
+        }
+        if (tt > 0) {
+            const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)] : lds[L.wbar + tc + tt - 1];
+            g -= w * res[bl * T1 + tt - 1];
+        }
+        return g;
+    }
+    case SK_S: return lds[L.As + ns * X + j];
+    case SK_LS_E: return lds[L.Qs + ns * X + j];
+    case SK_TT_G: return lds[L.As + ns + j] * bb_exp(lds[L.zs1 + j]);
+    case SK_LT_G: return lds[L.As + ns + j] * bb_exp(z) * lds[L.zs0 + j];
+    case SK_LS_G: return lds[L.Qs + ns + j];
+    case SK_TH_R: {
+        double a = 0.0;
+        for (int r = 0; r < M.R; ++r) a += lds[L.As + (ns + j) * M.R + r];
+        return a;
+    }
+    case SK_TT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(lds[L.zs1 + s.r * NB + j]);
+    case SK_LT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(z) * lds[L.zs0 + s.r * NB + j];
+    case SK_LS_R: return lds[L.Qs + (ns + j) * M.R + s.r];
+    case SK_GS: return lds[L.gglob + j];
+    default: return lds[L.gglob + M.nt1 + j];
+    }
+}
+
+// ================================================================================================
+// block_update: gradient of the log-joint for the tile's latents + optimiser step
+// ================================================================================================
+template <int KIND>
+BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    double* lds = cx.lds;
+    const BBTile t = bb_tile(M, A, cx.block, NB);
+    const unsigned long long step = S.ctr[A.par];
+    const int X = bb_xdim<KIND>(M);
+
+    BB_STAMP(cx, S, 8);
+    bb_finalize<false>(cx, M, S, A, L, S.zg);
+    BB_STAMP(cx, S, 10);
+
+    BBSeg* sg = (BBSeg*)(lds + L.seg);
+    int* li = (int*)(lds + L.misc);
+    BB_PASS(cx, tid) {
+        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
+    }
+    BB_SYNC(cx);
+    // stage: the saved draw of every tile latent back into LDS
+    BB_PASS(cx, tid) {
+        bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
+            if (s.kind >= SK_GS) return;
+            if (a0 && a1) {
+                const bb_d2 z = *(const bb_d2*)(S.zsv + i0);
+                lds[s.ldsoff + (i0 - s.lo)] = z.x;
+                lds[s.ldsoff + (i0 + 1 - s.lo)] = z.y;
+            } else if (a0) lds[s.ldsoff + (i0 - s.lo)] = S.zsv[i0];
+            else lds[s.ldsoff + (i0 + 1 - s.lo)] = S.zsv[i0 + 1];
+        });
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 11);
+    BB_PASS(cx, tid) { bb_effective_tables<KIND>(cx, tid, M, S, L, t, false); }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 12);
+
+    bb_pass_residuals_units<KIND>(cx, M, S, L, t, NB);
     // pass G: gather each latent's likelihood gradient from the LDS tables and update it
     BB_PASS(cx, tid) {
-        const int ns = t.nshift;
-        auto glik = [&](const BBSeg& s, long long j, double z) -> double {
-            switch (s.kind) {
-            case SK_L: {
-                const int r = s.r, T = M.T[r], T1 = T - 1, tc = M.tcum[r];
-                const double* res = lds + L.res + NB * (tc - r);
-                const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
-                const bool mut = bl >= ns;
-                const double lam = bb_exp(z);
-                const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
-                double g = cnt - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
-                if (tt < T1) {
-                    const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)] : lds[L.wbar + tc + tt];
-                    g += w * res[bl * T1 + tt];
-                }
-                if (tt > 0) {
-                    const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)] : lds[L.wbar + tc + tt - 1];
-                    g -= w * res[bl * T1 + tt - 1];
-                }
-                return g;
-            }
-            case SK_S: return lds[L.As + ns * X + j];
-            case SK_LS_E: return lds[L.Qs + ns * X + j];
-            case SK_TT_G: return lds[L.As + ns + j] * bb_exp(lds[L.zs1 + j]);
-            case SK_LT_G: return lds[L.As + ns + j] * bb_exp(z) * lds[L.zs0 + j];
-            case SK_LS_G: return lds[L.Qs + ns + j];
-            case SK_TH_R: {
-                double a = 0.0;
-                for (int r = 0; r < M.R; ++r) a += lds[L.As + (ns + j) * M.R + r];
-                return a;
-            }
-            case SK_TT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(lds[L.zs1 + s.r * NB + j]);
-            case SK_LT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(z) * lds[L.zs0 + s.r * NB + j];
-            case SK_LS_R: return lds[L.Qs + (ns + j) * M.R + s.r];
-            case SK_GS: return lds[L.gglob + j];
-            default: return lds[L.gglob + M.nt1 + j];
-            }
-        };
+        const BBSlot wslot = bb_slot_of(A, step);
+        auto glik = [&](const BBSeg& s, long long j, double z) -> double { return bb_glik<KIND>(lds, M, L, t, NB, s, j, z); };
         bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
             double z0 = 0.0, z1 = 0.0;
             if (a0 && a1) { const bb_d2 z = *(const bb_d2*)(S.zsv + i0); z0 = z.x; z1 = z.y; }
@@ -786,7 +850,7 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
             else z1 = S.zsv[i0 + 1];
             const double g0 = a0 ? glik(s, i0 - s.lo, z0) : 0.0;
             const double g1 = a1 ? glik(s, i0 + 1 - s.lo, z1) : 0.0;
-            bb_update_pair(M, S, A, step, s.blk, i0, a0, a1, z0, z1, g0, g1);
+            bb_update_pair(M, S, A, wslot, s.blk, i0, a0, a1, z0, z1, g0, g1);
         });
     }
     BB_SYNC(cx);
@@ -821,12 +885,13 @@ BB_DEV void bb_block_geno(BBCtx& cx, const DevModel& M, const DevState& S, const
     const int npairs = bb_seg_pairs(lo, hi);
     if (do_update) {
         const unsigned long long step = S.ctr[upd_par];
+        const BBSlot wslot = bb_slot_of(A, step);
         BB_PASS(cx, tid) {
             for (long long p = (long long)cx.block * cx.nthr + tid; p < npairs; p += (long long)nblocks * cx.nthr) {
                 const long long i0 = 2 * ((lo >> 1) + p);
                 const bool a0 = i0 >= lo, a1 = i0 + 1 < hi;
                 const double z0 = a0 ? S.zsv[i0] : 0.0, z1 = a1 ? S.zsv[i0 + 1] : 0.0;
-                bb_update_pair(M, S, A, step, BK_S, i0, a0, a1, z0, z1, a0 ? S.gsum[i0 - lo] : 0.0, a1 ? S.gsum[i0 + 1 - lo] : 0.0);
+                bb_update_pair(M, S, A, wslot, BK_S, i0, a0, a1, z0, z1, a0 ? S.gsum[i0 - lo] : 0.0, a1 ? S.gsum[i0 + 1 - lo] : 0.0);
             }
         }
         BB_SYNC(cx);

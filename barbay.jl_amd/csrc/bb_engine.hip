@@ -9,6 +9,7 @@
 //                                            the same block programs; test-only debugging aid)
 #include "../../include/barbay_hip.h"
 #include "bb_block.h"
+#include "bb_persist.h"
 
 #include <algorithm>
 #include <cmath>
@@ -17,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #ifndef BB_EMU
@@ -192,6 +194,7 @@ struct bb_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bb_ncclComm_t comm = nullptr;
 #endif
+    int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
     bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
     bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
 };
@@ -273,6 +276,142 @@ static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean,
     dp.inv_var = 0;
     dp.mean_e = dm;
     dp.inv_var_e = di;
+    return 0;
+}
+
+struct bb_handle;
+static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
+#ifndef BB_EMU
+static int launch_check();
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// persistent launch (bb_persist.h)
+// ------------------------------------------------------------------------------------------------
+#ifndef BB_EMU
+typedef void (*bb_persist_kernel)(DevModel, DevState, RunArgs, int, unsigned long long, int);
+static bb_persist_kernel persist_kernel(int kind, int P) {
+    switch (kind * 10 + P) {
+    case 1: return k_persist<0, 1>;   case 2: return k_persist<0, 2>;
+    case 11: return k_persist<1, 1>;  case 12: return k_persist<1, 2>;
+    case 31: return k_persist<3, 1>;  case 32: return k_persist<3, 2>;
+    default: return nullptr;
+    }
+}
+#endif
+
+// pairs a tile can hold: every segment contributes count/2 + 1 at most
+static long long tile_pairs_bound(const bb_handle* h) {
+    const DevModel& M = h->M;
+    const long long NB = h->NB;
+    long long p = 0;
+    for (int r = 0; r < M.R; ++r) p += NB * M.T[r] / 2 + 1;
+    if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
+    else if (M.kind == 2) p += 3 * (NB / 2 + 1);
+    else p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
+    p += 2 * (M.nt1 / 2 + 1);
+    return p;
+}
+
+static int setup_persistent(bb_handle* h) {
+    h->persist_P = 0;
+    const char* ev = getenv("BB_NO_PERSIST");
+    const bool want = h->o.launch_mode != 1 && !(ev && atoi(ev) > 0 && h->o.launch_mode == 0);
+    const char* why = nullptr;
+    if (h->o.samples_per_step != 1) why = "samples_per_step != 1";
+    else if (h->o.world_size != 1 || h->force_reduce) why = "sharded run";
+    else if (h->o.elbo_every != 0) why = "ELBO recording is on";
+    else if (h->M.kind == BB_MODEL_GENOTYPE) why = "genotype model (second exchange per step)";
+    int P = 0;
+    if (!why) {
+        P = (int)((tile_pairs_bound(h) + h->nthr - 1) / h->nthr);
+        if (P > 2) why = "tile too large for the register-resident state";
+    }
+#ifndef BB_EMU
+    if (!why && want) {
+        bb_persist_kernel k = persist_kernel(h->M.kind, P);
+        const int lds = (int)(h->lds_doubles * 8);
+        if (!k) why = "no kernel instance";
+        else {
+            if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                why = "cannot raise dynamic LDS";
+            int per_cu = 0, cus = 0;
+            hipDeviceProp_t pr;
+            if (!why && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, h->nthr, (size_t)lds) == hipSuccess &&
+                hipGetDeviceProperties(&pr, h->o.device) == hipSuccess) {
+                cus = pr.multiProcessorCount;
+                if ((long long)per_cu * cus < h->nblk) why = "grid does not fit resident on the device";
+            } else if (!why) why = "occupancy query failed";
+        }
+    }
+#endif
+    if (why) {
+        if (h->o.launch_mode == 2) return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2 (persistent) not possible: %s", why);
+        return 0;
+    }
+    if (want) h->persist_P = P;
+    return 0;
+}
+
+static int launch_persistent(bb_handle* h, long long nsteps) {
+    RunArgs A = make_args(h, h->step, 0, 1, true, false);
+    int rc = 0;
+#ifdef BB_EMU
+    const int P = h->persist_P;
+    std::vector<double> lds((size_t)h->nblk * (h->lds_doubles + 64));
+    auto run = [&](auto kindc, auto pc) {
+        constexpr int KIND = decltype(kindc)::value;
+        constexpr int PP = decltype(pc)::value;
+        std::vector<BBPst<PP>> st((size_t)h->nblk * h->nthr);
+        auto cxof = [&](int b) { return BBCtx{h->nthr, b, lds.data() + (size_t)b * (h->lds_doubles + 64)}; };
+        for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr); }
+        for (long long it = 0; it < nsteps; ++it) {
+            const unsigned long long step = (unsigned long long)(h->step + it);
+            for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_sample<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
+                                                  bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step); }
+            for (int g = 0; g < bbp_groups(h->nblk); ++g) { BBCtx cx = cxof(g); bbp_reduce_group(cx, h->M, h->S, A, h->NB, KIND, (int)(step & 1), g); }
+            for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step); }
+        }
+        for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_epilogue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, (unsigned long long)(h->step + nsteps)); }
+    };
+    auto byP = [&](auto kindc) {
+        if (P == 1) run(kindc, std::integral_constant<int, 1>{});
+        else run(kindc, std::integral_constant<int, 2>{});
+    };
+    switch (h->M.kind) {
+    case 0: byP(std::integral_constant<int, 0>{}); break;
+    case 1: byP(std::integral_constant<int, 1>{}); break;
+    default: byP(std::integral_constant<int, 3>{});
+    }
+    h->step += nsteps;
+#else
+    bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P);
+    while (nsteps > 0 && !rc) {
+        const int n = (int)std::min<long long>(nsteps, 4096);
+        BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
+        A = make_args(h, h->step, 0, 1, true, false);
+        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB,
+                           (unsigned long long)h->step, n);
+        rc = launch_check();
+        h->step += n;
+        nsteps -= n;
+    }
+#endif
+    return rc;
+}
+
+static int check_persistent(bb_handle* h) {
+#ifndef BB_EMU
+    unsigned g[4] = {0, 0, 0, 0};
+    int rc = d2h(g, h->S.gbar, sizeof g, h->stream);   // g[1] = timeout word
+    if (rc) return rc;
+    if (g[1] != 0) {
+        unsigned long long c[2];
+        if (!d2h(c, h->S.ctr, sizeof c, h->stream)) h->step = (long long)c[0];
+        return bb_fail(BB_ERR_DEVICE, "grid barrier of the persistent launch timed out (not all %d workgroups resident: device shared or masked?); "
+                                      "%lld steps completed; set launch_mode = 1", h->nblk, h->step);
+    }
+#endif
     return 0;
 }
 
@@ -511,9 +650,11 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &h->bak_mu, D + 2));
     BB_TRY(dalloc(h, &h->bak_om, D + 2));
     if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dp));
-    BB_TRY(dalloc(h, &S.partials, (size_t)M.K * (size_t)h->nblk));
+    BB_TRY(dalloc(h, &S.partials, (size_t)2 * M.K * (size_t)h->nblk));
     BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
-    BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
+    BB_TRY(dalloc(h, &S.zg, (size_t)4 * M.nt1));
+    BB_TRY(dalloc(h, &S.gbar, (size_t)32 * 10));
+    BB_TRY(dalloc(h, &S.xsum, (size_t)2 * M.K * 8));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));
@@ -534,6 +675,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         const double optb = opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD ? 64.0 : 32.0;
         h->bytes_update = (int64_t)((16.0 + 16.0 + optb) * Dsh + cnts);
     }
+    BB_TRY(setup_persistent(h));
     BB_TRY(bb_init_meanfield(h));
     *out = h;
     return BB_OK;
@@ -809,6 +951,12 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     int64_t done = 0;
 #ifndef BB_EMU
     BB_HIP(hipEventRecord(h->ev0, h->stream));
+#endif
+    if (h->persist_P > 0 && n_steps > 0) {
+        if ((rc = launch_persistent(h, n_steps))) return rc;
+        done = n_steps;
+    }
+#ifndef BB_EMU
     // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
     // pattern must repeat with the graph -> only when ELBO recording is off; no collectives inside.
     int gs = h->o.steps_per_graph == 0 ? 50 : h->o.steps_per_graph;
@@ -838,6 +986,7 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     BB_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_run_ms = ms;
 #endif
+    if (h->persist_P > 0 && (rc = check_persistent(h))) return rc;
     return check_finite(h);
 }
 

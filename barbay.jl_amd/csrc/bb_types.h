@@ -53,9 +53,9 @@ struct DevState {
     double *acc_mu, *acc_om;          // [D] optimiser accumulators
     double *hist;                     // [W][2][Dp] TruncatedADAGrad window of squared gradients
     double *gacc_mu, *gacc_om;        // [D] S > 1 accumulation / gradient export
-    double *partials;                 // [K][nblk]
+    double *partials;                 // [2][K][nblk] (second half: odd steps of the persistent launch)
     double *totals;                   // [K]
-    double *zg;                       // [2 nt1] sampled global latents
+    double *zg;                       // [2][2 nt1] sampled global latents (second half: odd steps, persistent launch)
     double *ztheta;                   // [G] sampled genotype fitness (genotype model)
     double *ds;                       // [nb] dlogp/ds_eff per mutant (genotype model)
     double *gsum;                     // [G] per-genotype sums of ds
@@ -64,6 +64,8 @@ struct DevState {
     double *elbo_sample;              // [S]
     unsigned long long *ctr;          // [2] device-side step counter (ping-pong)
     const double *eps_in;             // [S][D] caller-supplied draws (test hook) or nullptr
+    unsigned *gbar;                   // [32 * 10] exchange counters of the persistent launch (one 128-B line each)
+    double *xsum;                     // [2][K][8] per-group sums of the moment rows (persistent launch)
     unsigned long long *stamps;       // [nblk][32] s_memtime stamps (diagnostic build -DBB_STAMPS only)
 };
 

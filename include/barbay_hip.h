@@ -93,6 +93,9 @@ typedef struct bb_advi_opts {
     int32_t world_size;       /* number of shards (1 = whole problem)                    */
     int32_t steps_per_graph;  /* steps captured per hipGraph (0 = default, <0 = eager)   */
     int32_t elbo_every;       /* evaluate the ELBO every k-th step (0 = never)           */
+    int32_t launch_mode;      /* 0 = auto; 1 = two kernels per sample (graph / eager);
+                                 2 = one resident launch with a grid barrier per step (S = 1,
+                                 single GPU, no ELBO recording; error if not eligible)     */
 } bb_advi_opts;
 
 typedef struct bb_handle bb_handle;

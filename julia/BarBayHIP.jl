@@ -51,6 +51,7 @@ mutable struct bb_advi_opts
     world_size::Int32
     steps_per_graph::Int32
     elbo_every::Int32
+    launch_mode::Int32
     bb_advi_opts() = new()
 end
 

@@ -171,3 +171,21 @@ def case_errors(lib):
         bb.Engine("multienv", sp.counts, sp.n_neutral, sp.n_bc, _lib=lib)   # env_idx missing
     with pytest.raises(bb.BarBayHipError):
         bb.Engine("fitness", sp.counts, sp.n_neutral, sp.n_bc, samples_per_step=0, _lib=lib)
+
+
+def case_persistent_equals_two_kernel(lib, name, tol=1e-11, **geom):
+    """launch_mode 2 (one resident launch, state in registers, grid barrier per step) and launch_mode 1
+    (two kernels per sample) run the same arithmetic; also against the oracle with the exact window."""
+    sp = synth(name, seed=6)
+    outs = []
+    for mode in (1, 2):
+        with make_engine(sp, lib, seed=13, window=6, launch_mode=mode, **geom) as e:
+            mu0, om0 = e.get_params()
+            e.run(7)          # odd count, then a second call: state must survive leaving / re-entering the launch
+            e.run(10)
+            outs.append(e.get_params())
+            assert e.stats()["steps_done"] == 17
+    assert np.abs(outs[0][0] - outs[1][0]).max() < tol and np.abs(outs[0][1] - outs[1][1]).max() < tol
+    e, a, b, _ = _trajectory(lib, sp, 9, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
+    e.close()
+    assert a < 1e-10 and b < 1e-10, (a, b)

@@ -54,3 +54,23 @@ def test_launch_geometries(emu_lib, monkeypatch, nb, nthr):
     c.case_synth_grad(emu_lib, "replicate_ragged")
     c.case_trajectory_exact(emu_lib, "multienv", "TruncatedADAGrad", 2)
     c.case_trajectory_exact(emu_lib, "genotype", "DecayedADAGrad", 1)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d"])
+def test_persistent_equals_two_kernel(emu_lib, name):
+    c.case_persistent_equals_two_kernel(emu_lib, name)
+
+
+def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):
+    monkeypatch.setenv("BB_TUNE_NB", "120")     # 120 barcodes x (16 + 1 + 9) latents / 2 > 1024 pairs -> P = 2
+    monkeypatch.setenv("BB_TUNE_NTHR", "1024")
+    c.case_persistent_equals_two_kernel(emu_lib, "replicate_ragged")
+
+
+def test_persistent_not_eligible_is_an_error(emu_lib):
+    import barbay_jl_amd as bb
+    from conftest import make_engine
+    with pytest.raises(bb.BarBayHipError, match="persistent"):
+        make_engine(c.synth("genotype"), emu_lib, launch_mode=2)
+    with pytest.raises(bb.BarBayHipError, match="samples_per_step"):
+        make_engine(c.synth("multienv"), emu_lib, launch_mode=2, samples_per_step=2)

@@ -109,3 +109,28 @@ def test_rccl_path_single_rank(hip_lib, monkeypatch):
         e.run(25)
         got = e.get_params()
     assert np.abs(got[0] - ref[0]).max() < 1e-9 and np.abs(got[1] - ref[1]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d"])
+def test_persistent_equals_two_kernel(hip_lib, name):
+    c.case_persistent_equals_two_kernel(hip_lib, name)
+
+
+def test_persistent_two_pairs_per_thread(hip_lib, monkeypatch):
+    monkeypatch.setenv("BB_TUNE_NB", "120")
+    monkeypatch.setenv("BB_TUNE_NTHR", "1024")
+    c.case_persistent_equals_two_kernel(hip_lib, "replicate_ragged")
+
+
+def test_persistent_full_size_matches_two_kernel(hip_lib):
+    """C2 at full size: 256 resident workgroups, 120 steps incl. a window re-add, against launch_mode 1."""
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import port
+    sp = port.spec_from_workload(synth.fitness_normal(50_000, 8, 42))
+    outs = []
+    for mode in (1, 2):
+        with make_engine(sp, hip_lib, seed=42, launch_mode=mode) as e:
+            e.run(120)
+            outs.append(e.get_params())
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-9 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-9
