@@ -187,6 +187,7 @@ struct bb_handle {
     size_t dbg_cap = 0;
     bbStream stream{};
     double last_run_ms = 0, avg_sample_ms = 0, avg_update_ms = 0;
+    int launches_last_run = 0;
     int64_t bytes_sample = 0, bytes_update = 0;
 #ifndef BB_EMU
     hipGraphExec_t graph = nullptr;
@@ -195,6 +196,8 @@ struct bb_handle {
     bb_ncclComm_t comm = nullptr;
 #endif
     int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
+    DevModel* dM = nullptr;            // device copies of the descriptors for the persistent launch
+    DevState* dS = nullptr;
     bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
     bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
 };
@@ -289,12 +292,20 @@ static int launch_check();
 // persistent launch (bb_persist.h)
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_EMU
-typedef void (*bb_persist_kernel)(DevModel, DevState, RunArgs, int, unsigned long long, int);
-static bb_persist_kernel persist_kernel(int kind, int P) {
-    switch (kind * 10 + P) {
-    case 1: return k_persist<0, 1>;   case 2: return k_persist<0, 2>;
-    case 11: return k_persist<1, 1>;  case 12: return k_persist<1, 2>;
-    case 31: return k_persist<3, 1>;  case 32: return k_persist<3, 2>;
+typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, RunArgs, int, unsigned long long, int);
+static bb_persist_kernel persist_kernel(int kind, int P, int nthr) {
+    if (nthr > 512) {          // 16 waves per CU: 128 VGPRs per lane
+        switch (kind * 10 + P) {
+        case 1: return k_persist<0, 1, 1024>;   case 2: return k_persist<0, 2, 1024>;
+        case 11: return k_persist<1, 1, 1024>;  case 12: return k_persist<1, 2, 1024>;
+        case 31: return k_persist<3, 1, 1024>;  case 32: return k_persist<3, 2, 1024>;
+        default: return nullptr;
+        }
+    }
+    switch (kind * 10 + P) {   // <= 8 waves per CU: 256 VGPRs per lane, more pairs per thread
+    case 1: return k_persist<0, 1, 512>;   case 2: return k_persist<0, 2, 512>;   case 4: return k_persist<0, 4, 512>;
+    case 11: return k_persist<1, 1, 512>;  case 12: return k_persist<1, 2, 512>;  case 14: return k_persist<1, 4, 512>;
+    case 31: return k_persist<3, 1, 512>;  case 32: return k_persist<3, 2, 512>;  case 34: return k_persist<3, 4, 512>;
     default: return nullptr;
     }
 }
@@ -325,11 +336,12 @@ static int setup_persistent(bb_handle* h) {
     int P = 0;
     if (!why) {
         P = (int)((tile_pairs_bound(h) + h->nthr - 1) / h->nthr);
-        if (P > 2) why = "tile too large for the register-resident state";
+        if (P == 3) P = 4;
+        if (P > (h->nthr > 512 ? 2 : 4)) why = "tile too large for the register-resident state";
     }
 #ifndef BB_EMU
     if (!why && want) {
-        bb_persist_kernel k = persist_kernel(h->M.kind, P);
+        bb_persist_kernel k = persist_kernel(h->M.kind, P, h->nthr);
         const int lds = (int)(h->lds_doubles * 8);
         if (!k) why = "no kernel instance";
         else {
@@ -349,7 +361,12 @@ static int setup_persistent(bb_handle* h) {
         if (h->o.launch_mode == 2) return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2 (persistent) not possible: %s", why);
         return 0;
     }
-    if (want) h->persist_P = P;
+    if (want) {
+        h->persist_P = P;
+        int rc;
+        if ((rc = dalloc(h, &h->dM, 1)) || (rc = dalloc(h, &h->dS, 1))) return rc;
+        if ((rc = h2d(h->dM, &h->M, sizeof(DevModel), h->stream)) || (rc = h2d(h->dS, &h->S, sizeof(DevState), h->stream))) return rc;
+    }
     return 0;
 }
 
@@ -376,7 +393,8 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     };
     auto byP = [&](auto kindc) {
         if (P == 1) run(kindc, std::integral_constant<int, 1>{});
-        else run(kindc, std::integral_constant<int, 2>{});
+        else if (P == 2) run(kindc, std::integral_constant<int, 2>{});
+        else run(kindc, std::integral_constant<int, 4>{});
     };
     switch (h->M.kind) {
     case 0: byP(std::integral_constant<int, 0>{}); break;
@@ -385,12 +403,12 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     }
     h->step += nsteps;
 #else
-    bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P);
+    bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P, h->nthr);
     while (nsteps > 0 && !rc) {
         const int n = (int)std::min<long long>(nsteps, 4096);
         BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
         A = make_args(h, h->step, 0, 1, true, false);
-        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB,
+        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB,
                            (unsigned long long)h->step, n);
         rc = launch_check();
         h->step += n;
@@ -952,9 +970,11 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
 #ifndef BB_EMU
     BB_HIP(hipEventRecord(h->ev0, h->stream));
 #endif
+    h->launches_last_run = 0;
     if (h->persist_P > 0 && n_steps > 0) {
         if ((rc = launch_persistent(h, n_steps))) return rc;
         done = n_steps;
+        h->launches_last_run = (int)((n_steps + 4095) / 4096);
     }
 #ifndef BB_EMU
     // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
@@ -1151,6 +1171,8 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->n_blocks = h->nblk;
     s->block_threads = h->nthr;
     s->lds_bytes = (int32_t)(h->lds_doubles * 8);
+    s->persistent_pairs = h->persist_P;
+    s->launches_last_run = h->launches_last_run;
     return BB_OK;
 }
 

@@ -332,9 +332,11 @@ __device__ __forceinline__ bool bb_exchange(BBCtx& cx, const DevModel& M, const 
     return slot[0] != 0;
 }
 
-template <int KIND, int P>
-__global__ void __launch_bounds__(1024) k_persist(DevModel M, DevState S, RunArgs A, int NB, unsigned long long step0,
-                                                  int nsteps) {
+template <int KIND, int P, int NT>
+__global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, RunArgs A, int NB,
+                                                  unsigned long long step0, int nsteps) {
+    const DevModel& M = *Mp;   // descriptors live in device memory: scalar loads on demand instead of ~1.5 KB of
+    const DevState& S = *Sp;   // kernel arguments held (and spilled) in SGPRs across the whole step loop
     extern __shared__ __attribute__((aligned(16))) double bbp_smem[];
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bbp_smem};
     BBPst<P> st;

@@ -117,6 +117,8 @@ typedef struct bb_stats {
     double avg_sample_ms;      /* per-launch averages from the last bb_run_profiled      */
     double avg_update_ms;
     int32_t n_blocks, block_threads, lds_bytes;
+    int32_t persistent_pairs;  /* > 0: bb_run uses the resident launch with this many latent pairs per thread */
+    int32_t launches_last_run; /* kernel launches of the last bb_run (resident launch: <= 4096 steps each)       */
 } bb_stats;
 
 const char* bb_version(void);
