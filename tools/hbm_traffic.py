@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, CSV) into HBM bytes per step of
+the dominant kernel and writes profiles/hbm_traffic_latest.json (read by bench.py's `roofline.traffic`).
+
+Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes: counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide (16 B per lane) coalesced streaming read -> doubled;
+WRITE_SIZE is exact for 16 B per lane streaming stores.  Infinity-Cache hits appear to be counted, so this is
+fabric traffic beyond L2, an upper bound on HBM traffic."""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter_rows(d):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+def per_dispatch(rows, counter, kernel):
+    vals = {}
+    for r in rows:
+        if r.get("Counter_Name") == counter and kernel in r.get("Kernel_Name", ""):
+            vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return vals
+
+
+def main(fetch_dir, write_dir, kernel, steps, tag):
+    f = per_dispatch(counter_rows(fetch_dir), "FETCH_SIZE", kernel)
+    w = per_dispatch(counter_rows(write_dir), "WRITE_SIZE", kernel)
+    if not f or not w:
+        raise SystemExit(f"no {kernel} rows: fetch {len(f)} write {len(w)}")
+    fk, wk = max(f.values()), max(w.values())        # the timed launch is the longest one
+    fetch_b, write_b = 2.0 * fk * 1024.0, wk * 1024.0
+    out = {"kernel": kernel, "steps_in_launch": steps, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+           "hbm_bytes_per_step": (fetch_b + write_b) / steps, "fetch_bytes_per_step": fetch_b / steps,
+           "write_bytes_per_step": write_b / steps,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled (gfx950 "
+                   "under-reports 16 B/lane streaming reads by 2x); counts fabric traffic beyond L2 incl. Infinity-Cache hits",
+           "source": tag}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "")
