@@ -149,7 +149,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.As = o;   o += NB * X;
     L.Qs = o;   o += NB * X;
     L.acc = o;  o += (BB_NQ + 1) * nthr;
-    L.wk = o;   o += K;
+    L.wk = o;   o += K + 2 * nt1;
     L.Lt = o;   o += Ttot;
     L.invS = o; o += Ttot;
     L.cc = o;   o += Ttot;
@@ -604,9 +604,9 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
     BB_STAMP(cx, S, 6);
 }
 
-// Sum the moment rows and finish everything that depends on them (per replicate, tiny).
+// Fixed-order sum of the moment rows into lds[L.wk]; the sampled global latents into lds[L.zgl].
 template <bool COH>
-BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, const double* zg) {
+BB_DEV void bb_finalize_sum(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, const double* zg) {
     double* lds = cx.lds;
     // fixed-order sum of each moment row; the sampled global latents come along into LDS (gglob is free until
     // the finish writes the global gradients there)
@@ -650,6 +650,11 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
         }
     }
     BB_SYNC(cx);
+}
+
+// Everything that depends on the totals in lds[L.wk] and the sampled global latents in lds[L.zgl] (tiny).
+BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L) {
+    double* lds = cx.lds;
     BB_STAMP(cx, S, 9);
     // everything that depends on the totals, one (replicate, time) item per thread
     BB_PASS(cx, tid) {
@@ -704,6 +709,13 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
         }
     }
     BB_SYNC(cx);
+}
+
+// Sum the moment rows and finish everything that depends on them.
+template <bool COH>
+BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, const double* zg) {
+    bb_finalize_sum<COH>(cx, M, S, A, L, zg);
+    bb_finalize_finish(cx, M, S, A, L);
 }
 
 // passes R + U: residuals r = (l[t+1] - l[t]) - s_eff - c_t of every (barcode, time step), then the per-unit

@@ -382,13 +382,27 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
         std::vector<BBPst<PP>> st((size_t)h->nblk * h->nthr);
         auto cxof = [&](int b) { return BBCtx{h->nthr, b, lds.data() + (size_t)b * (h->lds_doubles + 64)}; };
         for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr); }
+        const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr);
+        memset(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4);
+        int ok = 1;
         for (long long it = 0; it < nsteps; ++it) {
             const unsigned long long step = (unsigned long long)(h->step + it);
-            for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_sample<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
-                                                  bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step); }
-            for (int g = 0; g < bbp_groups(h->nblk); ++g) { BBCtx cx = cxof(g); bbp_reduce_group(cx, h->M, h->S, A, h->NB, KIND, (int)(step & 1), g); }
-            for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step); }
+            const unsigned epoch = (unsigned)(it + 1);
+            const int par = (int)(step & 1);
+            for (int b = 0; b < h->nblk; ++b) {
+                BBCtx cx = cxof(b);
+                bbp_sample<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
+                bbp_publish_row(cx, h->M, h->S, L, epoch);
+            }
+            for (int g = 0; g < bbp_groups(h->nblk); ++g) { BBCtx cx = cxof(g); bbp_leader_reduce(cx, h->M, h->S, A, L, par, epoch, &ok); }
+            for (int b = 0; b < h->nblk; ++b) {
+                BBCtx cx = cxof(b);
+                bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
+                bbp_consume(cx, h->M, h->S, A, L, par, epoch, &ok);
+                bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
+            }
         }
+        if (!ok) rc = bb_fail(BB_ERR_DEVICE, "emulated exchange found a missing row");
         for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_epilogue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, (unsigned long long)(h->step + nsteps)); }
     };
     auto byP = [&](auto kindc) {
@@ -407,6 +421,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     while (nsteps > 0 && !rc) {
         const int n = (int)std::min<long long>(nsteps, 4096);
         BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
+        BB_HIP(hipMemsetAsync(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4, h->stream));
         A = make_args(h, h->step, 0, 1, true, false);
         hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB,
                            (unsigned long long)h->step, n);
@@ -626,8 +641,9 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         const size_t lds_cap = (size_t)160 * 1024 / (size_t)bpc;
         int nthr = 0;
         for (;;) {
-            const long long lat = (long long)NB * (M.Ttot + 2);
-            nthr = lat >= 1536 ? 1024 : (lat >= 768 ? 512 : 256);
+            const int per_mutant = M.kind == 0 ? 2 : (M.kind == 1 ? 2 * M.E : (M.kind == 2 ? 3 : 1 + 3 * M.R));
+            const long long pairs = (long long)NB * (M.Ttot + per_mutant) / 2;   // one pair of latents per thread is the sweet spot
+            nthr = pairs > 512 ? 1024 : (pairs > 256 ? 512 : 256);
             if ((ev = getenv("BB_TUNE_NTHR")) && atoi(ev) >= 64) nthr = atoi(ev) / 64 * 64;
             while (nthr < maxT) nthr <<= 1;
             const size_t need = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr).total * 8;
@@ -668,11 +684,13 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &h->bak_mu, D + 2));
     BB_TRY(dalloc(h, &h->bak_om, D + 2));
     if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dp));
-    BB_TRY(dalloc(h, &S.partials, (size_t)2 * M.K * (size_t)h->nblk));
+    BB_TRY(dalloc(h, &S.partials, (size_t)M.K * (size_t)h->nblk));
     BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
-    BB_TRY(dalloc(h, &S.zg, (size_t)4 * M.nt1));
+    BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
     BB_TRY(dalloc(h, &S.gbar, (size_t)32 * 10));
-    BB_TRY(dalloc(h, &S.xsum, (size_t)2 * M.K * 8));
+    BB_TRY(dalloc(h, &S.prow, (size_t)h->nblk * (M.K + 2 * M.nt1)));
+    BB_TRY(dalloc(h, &S.xrow, (size_t)2 * 8 * (M.K + 2 * M.nt1)));
+    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 16)));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));

@@ -16,6 +16,7 @@
 // update for all tiles, per step).
 #pragma once
 #include "bb_block.h"
+#include <string.h>
 
 template <int P>
 struct BBPst {
@@ -63,7 +64,7 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
     BBSeg* sg = (BBSeg*)(lds + L.seg);
     int* li = (int*)(lds + L.misc);
     BB_PASS(cx, tid) {
-        if (tid == 0) li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0);
+        if (tid == 0) { li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0); li[1] = 1; /* exchange ok word */ }
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
@@ -90,12 +91,14 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
-    const int par = (int)(step & 1);
-    double* zg = S.zg + (long long)par * 2 * M.nt1;
     BB_STAMP(cx, S, 20);
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
-        for (int k = tid; k < M.K; k += cx.nthr) lds[L.wk + k] = 0.0;
+        for (int k = tid; k < M.K + 2 * M.nt1; k += cx.nthr) lds[L.wk + k] = 0.0;
+    }
+    BB_SYNC(cx);
+    BB_PASS(cx, tid) {
+        BBPst<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
@@ -108,10 +111,10 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             st.z[k] = bb_d2{z0, z1};
             st.a[k] = bb_d2{e0 * sg0, e1 * sg1};
             st.h[k] = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
-            if (q.s.kind >= SK_GS) {       // replicated global latents: every tile's finalize needs them
-                double* dst = zg + (q.s.kind == SK_GLS ? M.nt1 : 0);
-                if (q.a0) bb_st<true>(dst + (q.i0 - q.s.lo), z0);
-                if (q.a1) bb_st<true>(dst + (q.i0 + 1 - q.s.lo), z1);
+            if (q.s.kind >= SK_GS) {       // replicated global latents (tile 0 only): they ride along in the tile's
+                double* dst = lds + L.wk + M.K + (q.s.kind == SK_GLS ? M.nt1 : 0);   // row, every other tile adds +0.0
+                if (q.a0) dst[q.i0 - q.s.lo] = z0;
+                if (q.a1) dst[q.i0 + 1 - q.s.lo] = z1;
             } else {
                 if (q.a0) lds[q.s.ldsoff + (q.i0 - q.s.lo)] = z0;
                 if (q.a1) lds[q.s.ldsoff + (q.i0 + 1 - q.s.lo)] = z1;
@@ -125,12 +128,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     BB_STAMP(cx, S, 22);
     bb_pass_moments<KIND>(cx, M, S, L, t, NB, false);
     BB_STAMP(cx, S, 23);
-    BB_PASS(cx, tid) {
-        double* dst = S.partials + (long long)par * M.K * A.nblk;
-        for (int k = tid; k < M.K; k += cx.nthr) bb_st<true>(dst + (long long)k * A.nblk + cx.block, lds[L.wk + k]);
-    }
     BB_STAMP(cx, S, 24);
-    // (the exchange that follows drains vmcnt and synchronises the workgroup)
 }
 
 // ---- window-slot prefetch: issued right after the tile has arrived at the exchange, so that the cold HBM
@@ -158,40 +156,120 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
     }
 }
 
-// ---- exchange: the tiles of group g (= workgroups b with b % NG == g; on MI355X the dispatcher deals
-// workgroups round-robin over the 8 XCDs, so a group shares an L2 -- speed only, never correctness) are
-// summed in member order by whichever member arrives last; every tile then reads NG rows instead of nblk.
+// ---- exchange of the tiles' rows (K moment rows + the 2 nt1 sampled global latents) ----------------------------
+// Two levels keep the bytes small and the summation order fixed: tile g (g < NG = min(8, tiles)) leads group
+// g = {tiles b : b % NG == g} (on MI355X workgroups are dealt round-robin over the 8 XCDs, so a group shares an
+// L2 -- speed only, never correctness), sums its members' rows in member order and publishes the group row;
+// every tile then adds the NG group rows in group order.
+// Hand-off (CDNA guide, R1 with the acquire replaced by sc1 loads): a row is stored write-through (sc1), every
+// storing wave drains vmcnt, the workgroup meets at a barrier, ONE lane stores the row's ready word = this
+// step's epoch (sc1).  A reader polls ONLY ready words (a few lanes: polling the rows themselves from 256 CUs
+// was ~15 MB of memory-side traffic per round), then reads the row once with sc1 loads in a single batch.
+// Ready words and rows are zeroed before every launch; epochs count steps within the launch (never 0); group
+// rows and their ready words are double-buffered by step parity (a slow reader of step s must not meet step
+// s+1's row); member rows need no double buffer (a member rewrites its row only after it has read every group
+// row of the previous step, which the leaders publish only after reading all member rows).  Every poll is bounded.
+typedef unsigned long long bb_u64;
+
 BB_DEV int bbp_groups(int nblk) { return nblk < 8 ? nblk : 8; }
 
-BB_DEV void bbp_reduce_group(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, int kind, int par, int g) {
-    const BBLds L = bb_lds_layout(M.R, M.E, kind, M.Ttot, M.nt1, M.K, NB, cx.nthr);
-    double* lds = cx.lds;
-    const int NG = bbp_groups(A.nblk);
-    const int members = (A.nblk - g + NG - 1) / NG;
-    const double* src = S.partials + (long long)par * M.K * A.nblk;
-    double* dst = S.xsum + (long long)par * M.K * NG;
-    double* tmp = lds + L.red;                      // 16 K doubles available, 4 K used
-    BB_PASS(cx, tid) {
-        for (int w = tid; w < M.K * 4; w += cx.nthr) {
-            const int k = w >> 2, c = w & 3;
-            const int per = (members + 3) / 4;
-            double v[8];
-            double s = 0.0;
-            for (int m0 = c * per; m0 < (c + 1) * per && m0 < members; m0 += 8) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = m0 + i;
-                    v[i] = (m < (c + 1) * per && m < members) ? bb_ld<true>(src + (long long)k * A.nblk + g + (long long)m * NG) : 0.0;
-                }
-                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+// Poll *word until it equals epoch; false = gave up (timeout word set).
+BB_DEV bool bb_wait_word(const unsigned* word, unsigned epoch, unsigned* tmo) {
+#ifdef BB_EMU
+    (void)tmo;
+    return *word == epoch;           // the emulation runs the phases in order: the row must already be there
+#else
+    for (unsigned spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 22)) {
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
             }
-            tmp[w] = s;
         }
     }
+    return true;
+#endif
+}
+
+BB_DEV void bb_drain_and_meet(BBCtx& cx) {
+#ifndef BB_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave: its write-through stores have landed
+#endif
     BB_SYNC(cx);
+}
+
+BB_DEV void bb_set_word(unsigned* word, unsigned v) {
+#ifdef BB_EMU
+    *word = v;
+#else
+    __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// this tile's row (complete in lds[L.wk .. + K + 2 nt1)) -> S.prow[b], then its ready word
+BB_DEV void bbp_publish_row(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, unsigned epoch) {
+    const int KK = M.K + 2 * M.nt1;
     BB_PASS(cx, tid) {
-        for (int k = tid; k < M.K; k += cx.nthr)
-            bb_st<true>(dst + (long long)k * NG + g, (tmp[4 * k] + tmp[4 * k + 1]) + (tmp[4 * k + 2] + tmp[4 * k + 3]));
+        for (int k = tid; k < KK; k += cx.nthr) bb_st<true>(S.prow + (long long)cx.block * KK + k, cx.lds[L.wk + k]);
+    }
+    bb_drain_and_meet(cx);
+    BB_STAMP(cx, S, 7);
+    BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
+}
+
+// leader of group g = tile g: wait for its members' rows, sum them in member order, publish the group row
+BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par,
+                              unsigned epoch, int* ok) {
+    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk), g = cx.block;
+    const int members = (A.nblk - g + NG - 1) / NG;
+    BB_PASS(cx, tid) {
+        if (tid < members && !bb_wait_word(S.rdy + 32 * (g + tid * NG), epoch, S.gbar + 1)) *ok = 0;
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 17);
+    // thread k owns row entry k: its members' values come straight into registers, 16 loads in flight (more would raise the kernel's register peak), and are
+    // added in member order (coalesced across k; no LDS staging, no extra barrier)
+    BB_PASS(cx, tid) {
+        for (int k = tid; k < KK; k += cx.nthr) {
+            double s = 0.0;
+            for (int m0 = 0; m0 < members; m0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    v[i] = (m0 + i < members) ? bb_ld<true>(S.prow + (long long)(g + (m0 + i) * NG) * KK + k) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += v[i];
+            }
+            bb_st<true>(S.xrow + ((long long)par * NG + g) * KK + k, s);
+        }
+    }
+    bb_drain_and_meet(cx);
+    BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * (A.nblk + par * NG + g), epoch); }
+    BB_STAMP(cx, S, 18);
+}
+
+// every tile: wait for the NG group rows, add them in group order -> totals in lds[L.wk], global samples in lds[L.zgl]
+BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par,
+                        unsigned epoch, int* ok) {
+    double* lds = cx.lds;
+    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk);
+    BB_PASS(cx, tid) {
+        if (tid < NG && !bb_wait_word(S.rdy + 32 * (A.nblk + par * NG + tid), epoch, S.gbar + 1)) *ok = 0;
+    }
+    BB_SYNC(cx);
+    BB_STAMP(cx, S, 1);
+    BB_PASS(cx, tid) {
+        for (int k = tid; k < KK; k += cx.nthr) {
+            double v[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v[g] = g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g) * KK + k) : 0.0;
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += v[g];
+            if (k < M.K) lds[L.wk + k] = s;
+            else lds[L.zgl + (k - M.K)] = s;
+        }
     }
     BB_SYNC(cx);
 }
@@ -205,12 +283,8 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
-    const int par = (int)(step & 1);
-    RunArgs Af = A;
-    Af.red = S.xsum + (long long)par * M.K * bbp_groups(A.nblk);
-    Af.nred = bbp_groups(A.nblk);
     BB_STAMP(cx, S, 25);
-    bb_finalize<true>(cx, M, S, Af, L, S.zg + (long long)par * 2 * M.nt1);
+    bb_finalize_finish(cx, M, S, A, L);
     BB_STAMP(cx, S, 26);
     bb_pass_residuals_units<KIND>(cx, M, S, L, t, NB);
     BB_STAMP(cx, S, 27);
@@ -284,54 +358,6 @@ BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const 
 }
 
 #ifndef BB_EMU
-// Exchange of the moment rows between the resident workgroups (zeroed counters before every launch;
-// epoch = step index within the launch + 1).  words: bar[0] = groups done, bar[1] = timeout, bar[32 (g+1)] =
-// arrivals of group g.  Every wait is bounded; on timeout all workgroups leave the step loop.
-__device__ __forceinline__ bool bb_wait_ge(unsigned* word, unsigned target, unsigned* tmo) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0u) {
-            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24)) {
-                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-    return true;
-}
-
-template <class F>
-__device__ __forceinline__ bool bb_exchange(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, int kind,
-                                            int par, unsigned epoch, int* slot /* LDS: [0] ok, [1] reducer */, F after_arrival) {
-    unsigned* bar = S.gbar;
-    const int NG = bbp_groups(A.nblk);
-    const int g = cx.block % NG;
-    const unsigned members = (unsigned)((A.nblk - g + NG - 1) / NG);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: write-through rows have landed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(bar + 32 * (g + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        slot[1] = (ticket == members * epoch - 1u);        // last arriver of the group in this epoch
-        slot[0] = 1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // rows are stored sc1 + drained and read with sc1 loads only
-    }
-    __syncthreads();
-    if (slot[1]) {                                         // uniform per workgroup
-        bbp_reduce_group(cx, M, S, A, NB, kind, par, g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    after_arrival();                                       // loads issued here fly while the tile waits
-    if (threadIdx.x == 0) {
-        slot[0] = bb_wait_ge(bar, (unsigned)NG * epoch, bar + 1) ? 1 : 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
-    return slot[0] != 0;
-}
-
 template <int KIND, int P, int NT>
 __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, RunArgs A, int NB,
                                                   unsigned long long step0, int nsteps) {
@@ -346,8 +372,16 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
     for (; done < nsteps; ++done) {
         const unsigned long long step = step0 + (unsigned long long)done;
         bbp_sample<KIND, P>(cx, M, S, A, NB, &st, step);
-        if (!bb_exchange(cx, M, S, A, NB, KIND, (int)(step & 1), (unsigned)(done + 1), ok_slot,
-                         [&]() { bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step); })) break;
+        {
+            const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+            const unsigned epoch = (unsigned)(done + 1);
+            const int par = (int)(step & 1);
+            bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
+            if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce(cx, M, S, A, L, par, epoch, ok_slot);
+            bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
+            bbp_consume(cx, M, S, A, L, par, epoch, ok_slot);
+            if (*ok_slot == 0) break;                                  // uniform: read after bbp_consume's barrier
+        }
         bbp_update<KIND, P>(cx, M, S, A, NB, &st, step);
     }
     bbp_epilogue<KIND, P>(cx, M, S, A, NB, &st, step0 + (unsigned long long)done);

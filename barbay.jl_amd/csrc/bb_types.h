@@ -65,7 +65,9 @@ struct DevState {
     unsigned long long *ctr;          // [2] device-side step counter (ping-pong)
     const double *eps_in;             // [S][D] caller-supplied draws (test hook) or nullptr
     unsigned *gbar;                   // [32 * 10] exchange counters of the persistent launch (one 128-B line each)
-    double *xsum;                     // [2][K][8] per-group sums of the moment rows (persistent launch)
+    double *prow;                     // [nblk][K + 2 nt1] rows of the tiles (persistent launch)
+    double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
+    unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
     unsigned long long *stamps;       // [nblk][32] s_memtime stamps (diagnostic build -DBB_STAMPS only)
 };
 

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""steps/s of every BASELINE.json config on ONE GPU (configs 4 and 5 are specified sharded over 4 / 8 GPUs; this
+is their single-GPU rate).  Prints one JSON line per config; not the driver's bench (that is bench.py on C2)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import barbay_jl_amd as bb  # noqa: E402
+from barbay_jl_amd import synth  # noqa: E402
+
+CFG = {
+    "C1 fitness_normal 15x5 (reference fixture shape)": lambda: synth.fitness_normal(15, 5, 1, n_neutral=5),
+    "C2 fitness_normal 50000x8": lambda: synth.fitness_normal(50_000, 8, 42),
+    "C3 replicate_fitness_normal 20000x6x3": lambda: synth.replicate_fitness_normal(20_000, 6, 3, 43),
+    "C4 multienv_fitness_normal 20000x6 E=4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
+    "C5 genotype_fitness_normal 200000x8 G=5000": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45),
+}
+steps = int(os.environ.get("STEPS", 2000))
+for name, mk in CFG.items():
+    wl = mk()
+    e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=1)
+    e.run(200)
+    t0 = time.perf_counter()
+    e.run(steps)
+    dt = time.perf_counter() - t0
+    st = e.stats()
+    print(json.dumps({"config": name, "steps_per_s": round(steps / dt, 1), "us_per_step": round(dt / steps * 1e6, 2),
+                      "n_latents": st["n_latents"], "bytes_per_step": st["bytes_per_step"],
+                      "frac_hbm_peak": round(st["bytes_per_step"] * steps / dt / 8e12, 4),
+                      "resident_launch_pairs": st["persistent_pairs"], "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
+          flush=True)
+    e.close()
