@@ -21,7 +21,7 @@
 template <int P>
 struct BBPst {
     bb_d2 mu[P], om[P], am[P], ao[P];   // variational parameters and optimiser accumulators of P pairs
-    bb_d2 z[P], a[P], h[P];             // current draw: z, eps*sigmoid(omega), sigmoid/softplus
+    bb_d2 a[P], h[P];                   // current draw: eps*sigmoid(omega), sigmoid/softplus (z itself stays staged in LDS)
     bb_d2 hm[P], ho[P];                 // this step's TruncatedADAGrad window slot, fetched while the exchange is in flight
 };
 
@@ -76,7 +76,7 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
             st.om[k] = bb_load_pair(S.om, q.i0, q.a0, q.a1);
             st.am[k] = bb_load_pair(S.acc_mu, q.i0, q.a0, q.a1);
             st.ao[k] = bb_load_pair(S.acc_om, q.i0, q.a0, q.a1);
-            st.z[k] = st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = bb_d2{0.0, 0.0};
+            st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = bb_d2{0.0, 0.0};
         }
     }
     BB_SYNC(cx);
@@ -108,7 +108,6 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             bb_softplus_sigmoid(st.om[k].x, &sp0, &sg0);
             bb_softplus_sigmoid(st.om[k].y, &sp1, &sg1);
             const double z0 = fma(sp0, e0, st.mu[k].x), z1 = fma(sp1, e1, st.mu[k].y);
-            st.z[k] = bb_d2{z0, z1};
             st.a[k] = bb_d2{e0 * sg0, e1 * sg1};
             st.h[k] = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
             if (q.s.kind >= SK_GS) {       // replicated global latents (tile 0 only): they ride along in the tile's
@@ -303,14 +302,18 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
             if (!q.valid) continue;
             const long long blo = M.blk_lo[q.s.blk];
+            // the draw is still staged in LDS (tile latents) / came back with the totals (replicated global latents)
+            const double* zsrc = q.s.kind >= SK_GS ? lds + L.zgl + (q.s.kind == SK_GLS ? M.nt1 : 0) : lds + q.s.ldsoff;
             double pm, iv, g0 = 0.0, g1 = 0.0;
             if (q.a0) {
+                const double z0 = zsrc[q.i0 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 - blo, &pm, &iv);
-                g0 = bb_glik<KIND>(lds, M, L, t, NB, q.s, q.i0 - q.s.lo, st.z[k].x) - (st.z[k].x - pm) * iv;
+                g0 = bb_glik<KIND>(lds, M, L, t, NB, q.s, q.i0 - q.s.lo, z0) - (z0 - pm) * iv;
             }
             if (q.a1) {
+                const double z1 = zsrc[q.i0 + 1 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 + 1 - blo, &pm, &iv);
-                g1 = bb_glik<KIND>(lds, M, L, t, NB, q.s, q.i0 + 1 - q.s.lo, st.z[k].y) - (st.z[k].y - pm) * iv;
+                g1 = bb_glik<KIND>(lds, M, L, t, NB, q.s, q.i0 + 1 - q.s.lo, z1) - (z1 - pm) * iv;
             }
             if (k == 0) BB_STAMP_W(cx, S, 30);
             const double go0 = fma(g0, st.a[k].x, st.h[k].x), go1 = fma(g1, st.a[k].y, st.h[k].y);
