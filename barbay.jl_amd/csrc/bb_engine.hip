@@ -192,6 +192,7 @@ struct bb_handle {
 #ifndef BB_EMU
     hipGraphExec_t graph = nullptr;
     int graph_steps = 0;
+    bool graph_failed = false;         // capture / instantiation failed once (e.g. a collective that cannot be captured): stay eager
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bb_ncclComm_t comm = nullptr;
 #endif
@@ -965,11 +966,15 @@ static int build_graph(bb_handle* h, int steps) {
     int rc = 0;
     for (int i = 0; i < steps && !rc; ++i) rc = enqueue_step(h, i);   // parity of i == parity of the real step (even start)
     hipError_t e = hipStreamEndCapture(h->stream, &g);
-    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess) return bb_fail(BB_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    if (rc || e != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        h->graph_failed = true;      // not an error: bb_run launches eagerly instead
+        return 0;
+    }
     e = hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { h->graph = nullptr; return bb_fail(BB_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { h->graph = nullptr; (void)hipGetLastError(); h->graph_failed = true; return 0; }
     h->graph_steps = steps;
     return 0;
 }
@@ -998,14 +1003,15 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
     // pattern must repeat with the graph -> only when ELBO recording is off; no collectives inside.
     int gs = h->o.steps_per_graph == 0 ? 50 : h->o.steps_per_graph;
-    const bool graph_ok = gs > 0 && h->o.world_size == 1 && !h->force_reduce && h->o.elbo_every == 0;
+    // (the RCCL all-reduce of a sharded run is captured too; if that capture fails once, launches stay eager)
+    const bool graph_ok = gs > 0 && h->o.elbo_every == 0 && !h->graph_failed && !getenv("BB_NO_GRAPH");
     if (graph_ok) {
         gs &= ~1;
         if (gs < 2) gs = 2;
         if ((h->step & 1) && done < n_steps) { if ((rc = enqueue_step(h, h->step))) return rc; h->step++; done++; }
         if (n_steps - done >= gs) {
             if ((rc = build_graph(h, gs))) return rc;
-            while (n_steps - done >= gs) {
+            while (h->graph && n_steps - done >= gs) {
                 BB_HIP(hipGraphLaunch(h->graph, h->stream));
                 h->step += gs;
                 done += gs;
