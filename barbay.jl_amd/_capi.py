@@ -41,6 +41,7 @@ class bb_model_desc(C.Structure):
         ("n_geno", C.c_int32), ("geno_idx", C.POINTER(C.c_int32)),
         ("s_pop_prior", bb_prior), ("logsigma_pop_prior", bb_prior), ("s_bc_prior", bb_prior),
         ("logsigma_bc_prior", bb_prior), ("loglambda_prior", bb_prior), ("logtau_prior", bb_prior),
+        ("flags", C.c_int32),
     ]
 
 
@@ -147,7 +148,7 @@ class Engine:
                  samples_per_step: int = 1, optimizer: str = "TruncatedADAGrad", eta: float = 0.1,
                  tau: float = 40.0, window: int = 100, resum_every: int = 0, pre: float = 1.0,
                  post: float = 0.9, seed: int = 0, device: int = 0, rank: int = 0, world_size: int = 1,
-                 steps_per_graph: int = 0, elbo_every: int = 0, launch_mode: int = 0, _lib: Optional[C.CDLL] = None):
+                 steps_per_graph: int = 0, elbo_every: int = 0, launch_mode: int = 0, ragged_method: bool = False, _lib: Optional[C.CDLL] = None):
         self._lib = _lib if _lib is not None else load_library()
         self._h = C.c_void_p()
         self.kind = kind
@@ -165,6 +166,7 @@ class Engine:
         md.kind = BB_MODEL[kind]
         md.n_rep = len(counts)
         md.n_neutral = int(n_neutral)
+        md.flags = 1 if ragged_method else 0      # BB_FLAG_RAGGED_METHOD
         md.n_bc = int(n_bc)
         nt = hold(np.asarray([c.shape[0] for c in counts], dtype=np.int32))
         md.n_time = _ptr(nt, C.POINTER(C.c_int32))

@@ -189,6 +189,18 @@ BB_DEV BBTile bb_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
     return t;
 }
 
+// Ragged replicate method (model_fitness_normal_hierarchical_replicates.jl:596-610): the neutral data vector is
+// time-fastest (:549) but its mean / variance vectors are `repeat(s_t[range], inner=n_neutral)` (:599-605), so
+// element e = t + (T-1) b is paired with population index j = e div n_neutral.
+BB_DEV int bb_qj(const DevModel& M, int T1, int t, long long b) { return (int)(((long long)t + (long long)T1 * b) / M.nn); }
+// neutrals b in [lo, hi) pair (t, j):  j nn <= t + T1 b < (j + 1) nn
+BB_DEV void bb_qrange(const DevModel& M, int T1, int t, int j, long long* lo, long long* hi) {
+    const long long a = (long long)j * M.nn - t, b = (long long)(j + 1) * M.nn - t;
+    long long l = a <= 0 ? 0 : (a + T1 - 1) / T1, h = b <= 0 ? 0 : (b + T1 - 1) / T1;
+    *lo = l > M.nn ? M.nn : l;
+    *hi = h > M.nn ? M.nn : h;
+}
+
 // which per-unit slot time step t of replicate r uses (environment of t+1 / replicate / 0)
 template <int KIND> BB_DEV int bb_xof(const DevModel& M, int r, int t) {
     return KIND == 1 ? M.env_idx[t + 1] : (KIND == 3 ? r : 0);
@@ -541,6 +553,32 @@ BB_DEV void bb_pass_moments(BBCtx& cx, const DevModel& M, const DevState& S, con
         }
         BB_SYNC(cx);
     }
+    if (KIND == 3 && M.quirk && t.nshift > 0) {
+        // ragged-method neutral pairing: sums of d = l[t+1] - l[t] and d^2 over the tile's neutrals of every
+        // (t, j) pair, one thread per pair, barcodes in order (deterministic); rows kqa[r] + 2 (t T1 + j) + {0, 1}
+        BB_PASS(cx, tid) {
+            for (int r = 0; r < M.R; ++r) {
+                const int T = M.T[r], T1 = T - 1;
+                const double* zl = lds + L.zl + NB * M.tcum[r];
+                for (int w = tid; w < T1 * T1; w += cx.nthr) {
+                    const int tt = w / T1, j = w - tt * T1;
+                    long long lo, hi;
+                    bb_qrange(M, T1, tt, j, &lo, &hi);
+                    if (lo < t.b0) lo = t.b0;
+                    if (hi > t.b0 + t.nshift) hi = t.b0 + t.nshift;
+                    double s1 = 0.0, s2 = 0.0;
+                    for (long long bb = lo; bb < hi; ++bb) {
+                        const int bl = (int)(bb - t.b0);
+                        const double d = zl[bl * T + tt + 1] - zl[bl * T + tt];
+                        s1 += d; s2 += d * d;
+                    }
+                    lds[L.wk + M.kqa[r] + 2 * w] = s1;
+                    lds[L.wk + M.kqa[r] + 2 * w + 1] = s2;
+                }
+            }
+        }
+        BB_SYNC(cx);
+    }
 }
 
 // ================================================================================================
@@ -681,14 +719,46 @@ BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, 
                 const double sbar = lds[L.zgl + M.off_t[r] + tt], ls = lds[L.zgl + M.nt1 + M.off_t[r] + tt];
                 const double wb = bb_exp(-2.0 * ls);
                 const double c = lds[L.Lt + j + 1] - lds[L.Lt + j] - sbar;
-                const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
                 const double quadM = M2 - 2.0 * c * M1 + c * c * M0;
-                Dt = (M1 - c * M0) + wb * (N1 - c * nn);
-                lds[L.gglob + M.off_t[r] + tt] = -Dt;
-                lds[L.gglob + M.nt1 + M.off_t[r] + tt] = wb * quadN - nn;
                 lds[L.cc + j] = c;
                 lds[L.wbar + j] = wb;
-                elb = -0.5 * (quadM + wb * quadN) - nn * ls;
+                if (!M.quirk) {
+                    const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
+                    Dt = (M1 - c * M0) + wb * (N1 - c * nn);
+                    lds[L.gglob + M.off_t[r] + tt] = -Dt;
+                    lds[L.gglob + M.nt1 + M.off_t[r] + tt] = wb * quadN - nn;
+                    elb = -0.5 * (quadM + wb * quadN) - nn * ls;
+                } else {
+                    // ragged method: this thread is time step tt for D_t (neutral element (tt, b) pairs index jq) and
+                    // population index tt for the global gradients (pairs (t', tt) over all t')
+                    const int T1 = T - 1;
+                    const double cL = lds[L.Lt + j + 1] - lds[L.Lt + j];
+                    double Dn = 0.0, gs = 0.0, gls = 0.0, en = 0.0;
+                    for (int q = 0; q < T1; ++q) {
+                        long long lo, hi;
+                        {   // D_t: neutrals at time tt paired with index q
+                            bb_qrange(M, T1, tt, q, &lo, &hi);
+                            const double n = (double)(hi - lo);
+                            const double* aa = lds + L.wk + M.kqa[r] + 2 * (tt * T1 + q);
+                            const double sq = lds[L.zgl + M.off_t[r] + q], wq = bb_exp(-2.0 * lds[L.zgl + M.nt1 + M.off_t[r] + q]);
+                            Dn += wq * (aa[0] - n * (cL - sq));
+                        }
+                        {   // gradients of s_pop[tt], logsigma_pop[tt]: neutrals at time q paired with index tt
+                            bb_qrange(M, T1, q, tt, &lo, &hi);
+                            const double n = (double)(hi - lo);
+                            const double* aa = lds + L.wk + M.kqa[r] + 2 * (q * T1 + tt);
+                            const double cq = (lds[L.Lt + M.tcum[r] + q + 1] - lds[L.Lt + M.tcum[r] + q]) - sbar;
+                            const double R1 = aa[0] - n * cq, R2 = aa[1] - 2.0 * cq * aa[0] + n * cq * cq;
+                            gs -= wb * R1;
+                            gls += wb * R2 - n;
+                            en += -0.5 * wb * R2 - n * ls;
+                        }
+                    }
+                    Dt = (M1 - c * M0) + Dn;
+                    lds[L.gglob + M.off_t[r] + tt] = -(M1 - c * M0) + gs;
+                    lds[L.gglob + M.nt1 + M.off_t[r] + tt] = gls;
+                    elb = -0.5 * quadM + en;
+                }
             }
             lds[L.Dt + j] = Dt;
             lds[L.elbt + j] = elb;
@@ -734,6 +804,8 @@ BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState
                 const int bl = T1 == 1 ? j : (int)bb_umulhi((unsigned)j, magic1), tt = j - bl * T1;
                 double a = zl[bl * T + tt + 1] - zl[bl * T + tt];
                 if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof<KIND>(M, r, tt)];
+                else if (KIND == 3 && M.quirk)   // residual against -s_pop[jq] instead of -s_pop[tt]
+                    a += lds[L.zgl + M.off_t[r] + bb_qj(M, T1, tt, t.b0 + bl)] - lds[L.zgl + M.off_t[r] + tt];
                 res[j] = a - lds[L.cc + tc + tt];
             }
         }
@@ -783,12 +855,15 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
         const double lam = bb_exp(z);
         const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
         double g = cnt - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
+        const bool qk = KIND == 3 && M.quirk && !mut;
         if (tt < T1) {
-            const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)] : lds[L.wbar + tc + tt];
+            const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)]
+                                 : lds[L.wbar + tc + (qk ? bb_qj(M, T1, tt, t.b0 + bl) : tt)];
             g += w * res[bl * T1 + tt];
         }
         if (tt > 0) {
-            const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)] : lds[L.wbar + tc + tt - 1];
+            const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)]
+                                 : lds[L.wbar + tc + (qk ? bb_qj(M, T1, tt - 1, t.b0 + bl) : tt - 1)];
             g -= w * res[bl * T1 + tt - 1];
         }
         return g;

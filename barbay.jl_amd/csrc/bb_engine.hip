@@ -477,6 +477,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     M.nn = md->n_neutral;
     M.nb = md->n_bc;
     M.B = M.nn + M.nb;
+    M.quirk = (md->kind == BB_MODEL_REPLICATE && (md->flags & BB_FLAG_RAGGED_METHOD)) ? 1 : 0;
     int rc = 0;
 #define BB_TRY(x)                  \
     do {                           \
@@ -507,10 +508,11 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         M.off_t[r] = M.nt1;
         M.cnt_off[r] = cnt;
         M.kq[r] = M.K;
+        M.kqa[r] = M.K + T + 5 * (T - 1);
         M.tcum[r] = M.Ttot;
         M.Ttot += T;
         M.nt1 += T - 1;
-        M.K += 6 * T - 5;
+        M.K += 6 * T - 5 + (M.quirk ? 2 * (T - 1) * (T - 1) : 0);
         n_l += (long long)T * M.B;
         cnt += (long long)T * M.B;
     }

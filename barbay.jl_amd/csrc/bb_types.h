@@ -36,6 +36,8 @@ struct DevModel {
     int off_t[BB_MAX_REP];            // first time step of replicate r inside s_pop / logsigma_pop
     long long cnt_off[BB_MAX_REP];    // offset of replicate r in counts
     int kq[BB_MAX_REP];               // first moment row of replicate r
+    int kqa[BB_MAX_REP];              // first row of replicate r's (t, j) neutral table (ragged-method pairing only)
+    int quirk;                        // 1 = ragged replicate method: neutral element (t, b) pairs population index (t + (T-1) b) div n_neutral
     int tcum[BB_MAX_REP];             // sum_{r' < r} T_r'
     int Ttot, nt1, K;
     long long blk_lo[BK_COUNT], blk_hi[BK_COUNT];

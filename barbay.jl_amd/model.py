@@ -124,9 +124,10 @@ def replicate_fitness_normal(R, n_t, n_neutral: int, n_bc: int, **kwargs) -> Bay
     """model_fitness_normal_hierarchical_replicates.jl: R is T x B x n_rep (:145-332) or a list of
     T_r x B matrices (:407-638); n_t is T x n_rep or a list of vectors.
 
-    The ragged method's neutral-likelihood ordering (`repeat(.., inner=n_neutral)`, :599-605) is
-    inconsistent with its data vector (:549) unless n_neutral == 1 or T_r == 2; this
-    engine evaluates the self-consistent form of the 3-D method (:307-311) for both."""
+    The ragged method pairs neutral data element (t, b) with population index (t + (T_r-1) b) div n_neutral
+    (`repeat(.., inner=n_neutral)`, :599-605, against a time-fastest data vector :549).  When R is a
+    list -- the call that dispatches to that method in the reference -- the engine reproduces this pairing as
+    written (BB_FLAG_RAGGED_METHOD); the 3-D call evaluates the 3-D method's self-consistent pairing (:307-311)."""
     ragged = isinstance(R, (list, tuple))
     if ragged:
         c = [np.asarray(r, dtype=np.int64) for r in R]

@@ -40,6 +40,14 @@ extern "C" {
 #define BB_MODEL_REPLICATE 3  /* replicate_fitness_normal  src/model_fitness_normal_hierarchical_replicates.jl:145-332 (3-D)
                                  and :407-638 (ragged); equal n_time[] == the 3-D method */
 
+/* bb_model_desc.flags */
+#define BB_FLAG_RAGGED_METHOD 1 /* BB_MODEL_REPLICATE called as the reference's Vector{Matrix} method
+                                  (src/model_fitness_normal_hierarchical_replicates.jl:407-638): its neutral
+                                  likelihood pairs data element (t, b) with population index
+                                  (t + (T_r-1) b) div n_neutral (`repeat(.., inner=n_neutral)`, :599-605, against a
+                                  time-fastest data vector :549).  Reproduced as written when this flag is set;
+                                  without it the 3-D method's self-consistent pairing (:307-311) is evaluated. */
+
 /* optimisers selectable at src/vi.jl:99 (AdvancedVI 0.2) */
 #define BB_OPT_TRUNCATED_ADAGRAD 0
 #define BB_OPT_DECAYED_ADAGRAD 1
@@ -73,6 +81,7 @@ typedef struct bb_model_desc {
     bb_prior logsigma_bc_prior;  /* default [0,1] */
     bb_prior loglambda_prior;    /* default [3,3] */
     bb_prior logtau_prior;       /* default [-2,1]; Vector form only (as in the reference) */
+    int32_t flags;               /* BB_FLAG_*                                              */
 } bb_model_desc;
 
 /* Turing.ADVI(samples_per_step, max_iters) + optimiser + engine options. */

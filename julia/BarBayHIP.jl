@@ -34,6 +34,7 @@ struct bb_model_desc
     logsigma_bc_prior::bb_prior
     loglambda_prior::bb_prior
     logtau_prior::bb_prior
+    flags::Int32
 end
 
 mutable struct bb_advi_opts
@@ -109,7 +110,8 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
                            isempty(geno_idx) ? 0 : maximum(geno_idx) + 1,
                            isempty(geno_idx) ? C_NULL : pointer(geno_idx),
                            pr(:s_pop_prior), pr(:logσ_pop_prior), pr(:s_bc_prior), pr(:logσ_bc_prior),
-                           pr(:logλ_prior), pr(:logτ_prior))
+                           pr(:logλ_prior), pr(:logτ_prior),
+                           Int32(R isa Vector ? 1 : 0))   # BB_FLAG_RAGGED_METHOD: the Vector{Matrix} method was dispatched
         check(ccall((:bb_create, LIB), Cint, (Ref{bb_model_desc}, Ref{bb_advi_opts}, Ref{Ptr{Cvoid}}), md, opts, h))
     end
     try

@@ -189,3 +189,32 @@ def case_persistent_equals_two_kernel(lib, name, tol=1e-11, **geom):
     e, a, b, _ = _trajectory(lib, sp, 9, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
     e.close()
     assert a < 1e-10 and b < 1e-10, (a, b)
+
+
+def case_ragged_method(lib, launch_mode=0):
+    """BB_FLAG_RAGGED_METHOD reproduces the ragged replicate method's neutral pairing exactly as the reference
+    writes it (oracle/literal.py ragged_quirk=True, model_fitness_normal_hierarchical_replicates.jl:596-610)."""
+    for name, seed in (("replicate_ragged", 5), ("replicate_3d", 6)):
+        sp = synth(name, seed=seed)
+        sp2 = fixtures.synthetic("replicate", B=90, T=[4, 6, 3], n_rep=3, n_neutral=37, seed=seed) if name == "replicate_ragged" else sp
+        for spx in (sp, sp2):
+            with make_engine(spx, lib, seed=9, ragged_method=True, window=5, resum_every=1, launch_mode=launch_mode) as e:
+                mu0, om0 = advi.meanfield_init(9, spx.D)
+                mu, om = mu0 * 0.2 + 3, om0 * 0.5 - 2
+                eps = np.stack([rng.normals(9, 4, s, spx.D) for s in range(2)])
+                el, gm, go = literal.elbo_and_grad(mu, om, eps, spx, ragged_quirk=True)
+                el2, gm2, go2 = e.elbo_grad(mu, om, eps)
+                assert abs(el - el2) <= 50 * ELBO_RTOL * abs(el), (el, el2)
+                assert np.abs(gm - gm2).max() <= GRAD_RTOL * np.abs(gm).max()
+                assert np.abs(go - go2).max() <= GRAD_RTOL * np.abs(go).max()
+                # and it differs from the consistent pairing
+                el3, _, _ = literal.elbo_and_grad(mu, om, eps, spx)
+                if spx.n_neutral > 1:      # the pairings coincide when n_neutral == 1 (or T_r == 2)
+                    assert abs(el3 - el2) > 1e-9 * abs(el2)
+                # optimiser trajectory against the oracle loop
+                m0, o0 = e.get_params()
+                e.run(9)
+                m1, o1 = e.get_params()
+                f = lambda m, o, ee: literal.elbo_and_grad(m, o, ee, spx, ragged_quirk=True)
+                m2, o2, _ = advi.run_advi(spx, f, m0, o0, 9, 1, advi.TruncatedADAGrad(n=5), 9)
+                assert np.abs(m1 - m2).max() < 1e-10 and np.abs(o1 - o2).max() < 1e-10

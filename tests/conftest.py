@@ -32,6 +32,7 @@ def hip_lib():
 
 
 def make_engine(sp, lib=None, use_priors=False, **kw):
+    """kw may carry ragged_method=True (the reference's Vector{Matrix} replicate method)."""
     import barbay_jl_amd as bb
     return bb.Engine(sp.kind, sp.counts, sp.n_neutral, sp.n_bc, env_idx=sp.env_idx, geno_idx=sp.geno_idx,
                      priors=sp.priors if use_priors else None, _lib=lib, **kw)

@@ -74,3 +74,15 @@ def test_persistent_not_eligible_is_an_error(emu_lib):
         make_engine(c.synth("genotype"), emu_lib, launch_mode=2)
     with pytest.raises(bb.BarBayHipError, match="samples_per_step"):
         make_engine(c.synth("multienv"), emu_lib, launch_mode=2, samples_per_step=2)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_ragged_method_pairing(emu_lib, mode):
+    c.case_ragged_method(emu_lib, mode)
+
+
+def test_ragged_method_neutrals_across_tiles(emu_lib, monkeypatch):
+    monkeypatch.setenv("BB_TUNE_NB", "16")      # 37 neutrals span three tiles: the (t, j) table is summed over tiles
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    c.case_ragged_method(emu_lib, 1)
+    c.case_ragged_method(emu_lib, 2)

@@ -167,3 +167,8 @@ def test_full_size_other_configs(hip_lib, cfg):
             got = e.get_params()
         # elbo_every only adds the ELBO reduction, the parameter arithmetic is the same
         assert np.abs(got[0] - ref[0]).max() < 1e-8 and np.abs(got[1] - ref[1]).max() < 1e-8
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_ragged_method_pairing(hip_lib, mode):
+    c.case_ragged_method(hip_lib, mode)
