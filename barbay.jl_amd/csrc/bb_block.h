@@ -691,6 +691,7 @@ BB_DEV void bb_finalize_sum(BBCtx& cx, const DevModel& M, const DevState& S, con
 }
 
 // Everything that depends on the totals in lds[L.wk] and the sampled global latents in lds[L.zgl] (tiny).
+template <int KIND>
 BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L) {
     double* lds = cx.lds;
     BB_STAMP(cx, S, 9);
@@ -722,7 +723,7 @@ BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, 
                 const double quadM = M2 - 2.0 * c * M1 + c * c * M0;
                 lds[L.cc + j] = c;
                 lds[L.wbar + j] = wb;
-                if (!M.quirk) {
+                if (!(KIND == 3 && M.quirk)) {
                     const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
                     Dt = (M1 - c * M0) + wb * (N1 - c * nn);
                     lds[L.gglob + M.off_t[r] + tt] = -Dt;
@@ -782,10 +783,10 @@ BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, 
 }
 
 // Sum the moment rows and finish everything that depends on them.
-template <bool COH>
+template <int KIND, bool COH>
 BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, const double* zg) {
     bb_finalize_sum<COH>(cx, M, S, A, L, zg);
-    bb_finalize_finish(cx, M, S, A, L);
+    bb_finalize_finish<KIND>(cx, M, S, A, L);
 }
 
 // passes R + U: residuals r = (l[t+1] - l[t]) - s_eff - c_t of every (barcode, time step), then the per-unit
@@ -898,7 +899,7 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
     const int X = bb_xdim<KIND>(M);
 
     BB_STAMP(cx, S, 8);
-    bb_finalize<false>(cx, M, S, A, L, S.zg);
+    bb_finalize<KIND, false>(cx, M, S, A, L, S.zg);
     BB_STAMP(cx, S, 10);
 
     BBSeg* sg = (BBSeg*)(lds + L.seg);

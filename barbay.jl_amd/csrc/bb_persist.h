@@ -283,7 +283,7 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
     BB_STAMP(cx, S, 25);
-    bb_finalize_finish(cx, M, S, A, L);
+    bb_finalize_finish<KIND>(cx, M, S, A, L);
     BB_STAMP(cx, S, 26);
     bb_pass_residuals_units<KIND>(cx, M, S, L, t, NB);
     BB_STAMP(cx, S, 27);
