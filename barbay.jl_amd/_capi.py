@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbarbay_hip.so")
 
-BB_MODEL = {"fitness": 0, "multienv": 1, "genotype": 2, "replicate": 3}
+BB_MODEL = {"fitness": 0, "multienv": 1, "genotype": 2, "replicate": 3, "multienv_replicate": 4}
 BB_OPT_TRUNCATED_ADAGRAD = 0
 BB_OPT_DECAYED_ADAGRAD = 1
 BB_COMM_ID_BYTES = 128
@@ -176,6 +176,8 @@ class Engine:
         md.counts = _ptr(cflat, C.POINTER(C.c_int64))
         md.totals = _ptr(tflat, C.POINTER(C.c_int64))
         if env_idx is not None:
+            if isinstance(env_idx, (list, tuple)) and len(env_idx) and np.ndim(env_idx[0]) == 1:
+                env_idx = np.concatenate([np.asarray(x) for x in env_idx])     # one list per replicate -> replicate-major
             e = hold(np.ascontiguousarray(env_idx, dtype=np.int32))
             md.n_env = int(e.max()) + 1
             md.env_idx = _ptr(e, C.POINTER(C.c_int32))

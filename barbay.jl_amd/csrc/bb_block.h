@@ -128,7 +128,7 @@ struct BBLds {
     int total;
 };
 
-template <int KIND> BB_DEV int bb_xdim(const DevModel& M) { return KIND == 1 ? M.E : M.R; }
+template <int KIND> BB_DEV int bb_xdim(const DevModel& M) { return KIND == 1 ? M.E : (KIND == 4 ? M.E * M.R : M.R); }
 
 static inline
 #ifndef BB_EMU
@@ -136,13 +136,13 @@ __host__ __device__
 #endif
 BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, int nthr) {
     BBLds L;
-    int X = (kind == 1) ? E : R;
+    int X = (kind == 1) ? E : (kind == 4 ? E * R : R);
     int o = 0;
     L.zl = o;   o += NB * Ttot;
     L.zs0 = o;  o += NB * X;
     L.zs1 = o;  o += NB * X;
     L.zs2 = o;  o += NB * X;
-    L.zs3 = o;  o += NB;
+    L.zs3 = o;  o += NB * (kind == 4 ? E : 1);
     L.seff = o; o += NB * X;
     L.weff = o; o += NB * X;
     L.res = o;  o += NB * (Ttot - R);
@@ -203,7 +203,7 @@ BB_DEV void bb_qrange(const DevModel& M, int T1, int t, int j, long long* lo, lo
 
 // which per-unit slot time step t of replicate r uses (environment of t+1 / replicate / 0)
 template <int KIND> BB_DEV int bb_xof(const DevModel& M, int r, int t) {
-    return KIND == 1 ? M.env_idx[t + 1] : (KIND == 3 ? r : 0);
+    return KIND == 1 ? M.env_idx[t + 1] : (KIND == 3 ? r : (KIND == 4 ? r * M.E + M.env_idx[M.tcum[r] + t + 1] : 0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,12 +245,14 @@ BB_DEV int bb_build_segs(BBSeg* sg, const DevModel& M, const BBLds& L, const BBT
             add(BK_TT, SK_TT_G, M.blk_lo[BK_TT] + t.m0, t.nmt, L.zs0, 0);
             add(BK_LT, SK_LT_G, M.blk_lo[BK_LT] + t.m0, t.nmt, L.zs1, 0);
             add(BK_LS, SK_LS_G, M.blk_lo[BK_LS] + t.m0, t.nmt, L.zs2, 0);
-        } else {
-            add(BK_S, SK_TH_R, M.blk_lo[BK_S] + t.m0, t.nmt, L.zs3, 0);
+        } else {   // replicate (E_ = 1) and multienv_replicate: theta[e, m]; per replicate tt / lt / ls [e, m, r], env fastest
+            const int E_ = KIND == 4 ? M.E : 1;
+            add(BK_S, SK_TH_R, M.blk_lo[BK_S] + t.m0 * E_, (long long)t.nmt * E_, L.zs3, 0);
             for (int r = 0; r < M.R; ++r) {
-                add(BK_TT, SK_TT_R, M.blk_lo[BK_TT] + r * M.nb + t.m0, t.nmt, L.zs0 + r * t.NB, r);
-                add(BK_LT, SK_LT_R, M.blk_lo[BK_LT] + r * M.nb + t.m0, t.nmt, L.zs1 + r * t.NB, r);
-                add(BK_LS, SK_LS_R, M.blk_lo[BK_LS] + r * M.nb + t.m0, t.nmt, L.zs2 + r * t.NB, r);
+                const long long o = ((long long)r * M.nb + t.m0) * E_;
+                add(BK_TT, SK_TT_R, M.blk_lo[BK_TT] + o, (long long)t.nmt * E_, L.zs0 + r * t.NB * E_, r);
+                add(BK_LT, SK_LT_R, M.blk_lo[BK_LT] + o, (long long)t.nmt * E_, L.zs1 + r * t.NB * E_, r);
+                add(BK_LS, SK_LS_R, M.blk_lo[BK_LS] + o, (long long)t.nmt * E_, L.zs2 + r * t.NB * E_, r);
             }
         }
     }
@@ -467,15 +469,23 @@ BB_DEV double bb_effective_tables(BBCtx& cx, int tid, const DevModel& M, const D
             else if (KIND == 2) {
                 se = S.ztheta[M.geno_idx[t.m0 + ml]] + bb_exp(lds[L.zs1 + ml]) * lds[L.zs0 + ml];
                 ls = lds[L.zs2 + ml];
-            } else {
+            } else if (KIND == 3) {
                 se = lds[L.zs3 + ml] + bb_exp(lds[L.zs1 + x * t.NB + ml]) * lds[L.zs0 + x * t.NB + ml];
                 ls = lds[L.zs2 + x * t.NB + ml];
+            } else {   // multienv_replicate: x = r E + e   (model_multienv_..._replicates.jl:241, 311-312)
+                const int r = x / M.E, e = x - r * M.E, o = r * t.NB * M.E + ml * M.E + e;
+                se = lds[L.zs3 + ml * M.E + e] + bb_exp(lds[L.zs1 + o]) * lds[L.zs0 + o];
+                ls = lds[L.zs2 + o];
             }
             we = bb_exp(-2.0 * ls);
             if (want_elbo) {
                 int cnt;
                 if (KIND == 1) { cnt = 0; for (int tt = 0; tt < M.T[0] - 1; ++tt) cnt += (M.env_idx[tt + 1] == x); }
-                else cnt = M.T[KIND == 3 ? x : 0] - 1;
+                else if (KIND == 4) {
+                    const int r = x / M.E, e = x - r * M.E;
+                    cnt = 0;
+                    for (int tt = 0; tt < M.T[r] - 1; ++tt) cnt += (M.env_idx[M.tcum[r] + tt + 1] == e);
+                } else cnt = M.T[KIND == 3 ? x : 0] - 1;
                 el -= ls * cnt;
             }
         }
@@ -821,11 +831,12 @@ BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState
             double as = 0.0, qs = 0.0;
             if (bl >= t.nshift) {
                 const double w = lds[L.weff + u];
-                const int r = KIND == 3 ? x : 0;
+                const int r = KIND == 3 ? x : (KIND == 4 ? x / M.E : 0);
                 const int T1 = M.T[r] - 1;
                 const double* res = lds + L.res + NB * (M.tcum[r] - r) + bl * T1;
                 for (int tt = 0; tt < T1; ++tt) {
                     if (KIND == 1 && M.env_idx[tt + 1] != x) continue;
+                    if (KIND == 4 && M.env_idx[M.tcum[r] + tt + 1] != x - r * M.E) continue;
                     const double rr = res[tt];
                     as += w * rr;
                     qs += w * rr * rr - 1.0;
@@ -874,14 +885,20 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
     case SK_TT_G: return lds[L.As + ns + j] * bb_exp(lds[L.zs1 + j]);
     case SK_LT_G: return lds[L.As + ns + j] * bb_exp(z) * lds[L.zs0 + j];
     case SK_LS_G: return lds[L.Qs + ns + j];
-    case SK_TH_R: {
-        double a = 0.0;
-        for (int r = 0; r < M.R; ++r) a += lds[L.As + (ns + j) * M.R + r];
-        return a;
+    case SK_TH_R: case SK_TT_R: case SK_LT_R: case SK_LS_R: {
+        // j = ml E_ + e inside the segment (E_ = 1 for the replicate model); unit slot (ns + ml) X + r E_ + e
+        const int E_ = KIND == 4 ? M.E : 1;
+        const int ml = (int)j / E_, e = (int)j - ml * E_;
+        if (s.kind == SK_TH_R) {
+            double a = 0.0;
+            for (int r = 0; r < M.R; ++r) a += lds[L.As + (ns + ml) * X + r * E_ + e];
+            return a;
+        }
+        const int slot = (ns + ml) * X + s.r * E_ + e, o = s.r * NB * E_ + (int)j;
+        if (s.kind == SK_TT_R) return lds[L.As + slot] * bb_exp(lds[L.zs1 + o]);
+        if (s.kind == SK_LT_R) return lds[L.As + slot] * bb_exp(z) * lds[L.zs0 + o];
+        return lds[L.Qs + slot];
     }
-    case SK_TT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(lds[L.zs1 + s.r * NB + j]);
-    case SK_LT_R: return lds[L.As + (ns + j) * M.R + s.r] * bb_exp(z) * lds[L.zs0 + s.r * NB + j];
-    case SK_LS_R: return lds[L.Qs + (ns + j) * M.R + s.r];
     case SK_GS: return lds[L.gglob + j];
     default: return lds[L.gglob + M.nt1 + j];
     }

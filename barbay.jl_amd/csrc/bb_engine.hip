@@ -106,10 +106,10 @@ __global__ void __launch_bounds__(1024) k_update(DevModel M, DevState S, RunArgs
 }
 typedef void (*bb_step_kernel)(DevModel, DevState, RunArgs, int);
 static bb_step_kernel sample_kernel(int kind) {
-    switch (kind) { case 0: return k_sample<0>; case 1: return k_sample<1>; case 2: return k_sample<2>; default: return k_sample<3>; }
+    switch (kind) { case 0: return k_sample<0>; case 1: return k_sample<1>; case 2: return k_sample<2>; case 3: return k_sample<3>; default: return k_sample<4>; }
 }
 static bb_step_kernel update_kernel(int kind) {
-    switch (kind) { case 0: return k_update<0>; case 1: return k_update<1>; case 2: return k_update<2>; default: return k_update<3>; }
+    switch (kind) { case 0: return k_update<0>; case 1: return k_update<1>; case 2: return k_update<2>; case 3: return k_update<3>; default: return k_update<4>; }
 }
 __global__ void __launch_bounds__(256) k_geno(DevModel M, DevState S, RunArgs A, int do_update, int do_sample, int upd_par) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
@@ -300,6 +300,7 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr) {
         case 1: return k_persist<0, 1, 1024>;   case 2: return k_persist<0, 2, 1024>;
         case 11: return k_persist<1, 1, 1024>;  case 12: return k_persist<1, 2, 1024>;
         case 31: return k_persist<3, 1, 1024>;  case 32: return k_persist<3, 2, 1024>;
+        case 41: return k_persist<4, 1, 1024>;  case 42: return k_persist<4, 2, 1024>;
         default: return nullptr;
         }
     }
@@ -307,6 +308,7 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr) {
     case 1: return k_persist<0, 1, 512>;   case 2: return k_persist<0, 2, 512>;   case 4: return k_persist<0, 4, 512>;
     case 11: return k_persist<1, 1, 512>;  case 12: return k_persist<1, 2, 512>;  case 14: return k_persist<1, 4, 512>;
     case 31: return k_persist<3, 1, 512>;  case 32: return k_persist<3, 2, 512>;  case 34: return k_persist<3, 4, 512>;
+    case 41: return k_persist<4, 1, 512>;  case 42: return k_persist<4, 2, 512>;  case 44: return k_persist<4, 4, 512>;
     default: return nullptr;
     }
 }
@@ -320,7 +322,8 @@ static long long tile_pairs_bound(const bb_handle* h) {
     for (int r = 0; r < M.R; ++r) p += NB * M.T[r] / 2 + 1;
     if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
     else if (M.kind == 2) p += 3 * (NB / 2 + 1);
-    else p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
+    else if (M.kind == 3) p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
+    else p += (NB * M.E / 2 + 1) + 3ll * M.R * (NB * M.E / 2 + 1);
     p += 2 * (M.nt1 / 2 + 1);
     return p;
 }
@@ -414,7 +417,8 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     switch (h->M.kind) {
     case 0: byP(std::integral_constant<int, 0>{}); break;
     case 1: byP(std::integral_constant<int, 1>{}); break;
-    default: byP(std::integral_constant<int, 3>{});
+    case 3: byP(std::integral_constant<int, 3>{}); break;
+    default: byP(std::integral_constant<int, 4>{});
     }
     h->step += nsteps;
 #else
@@ -452,10 +456,10 @@ static int check_persistent(bb_handle* h) {
 extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
     if (!md || !opts || !out) return bb_fail(BB_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (md->kind < 0 || md->kind > 3) return bb_fail(BB_ERR_INVALID, "unknown model kind %d", md->kind);
+    if (md->kind < 0 || md->kind > 4) return bb_fail(BB_ERR_INVALID, "unknown model kind %d", md->kind);
     if (md->n_rep < 1 || md->n_rep > BB_MAX_REP) return bb_fail(BB_ERR_INVALID, "n_rep must be in 1..%d", BB_MAX_REP);
-    if (md->kind != BB_MODEL_REPLICATE && md->n_rep != 1)
-        return bb_fail(BB_ERR_INVALID, "only replicate_fitness_normal takes n_rep > 1");
+    if (md->kind != BB_MODEL_REPLICATE && md->kind != BB_MODEL_MULTIENV_REPLICATE && md->n_rep != 1)
+        return bb_fail(BB_ERR_INVALID, "only the replicate models take n_rep > 1");
     if (md->n_neutral < 1 || md->n_bc < 1) return bb_fail(BB_ERR_INVALID, "need at least one neutral and one mutant barcode");
     if (!md->n_time || !md->counts || !md->totals) return bb_fail(BB_ERR_INVALID, "n_time/counts/totals missing");
     if (opts->samples_per_step < 1) return bb_fail(BB_ERR_INVALID, "samples_per_step must be >= 1");
@@ -472,7 +476,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     DevModel& M = h->M;
     M.kind = md->kind;
     M.R = md->n_rep;
-    M.E = md->kind == BB_MODEL_MULTIENV ? md->n_env : 1;
+    M.E = (md->kind == BB_MODEL_MULTIENV || md->kind == BB_MODEL_MULTIENV_REPLICATE) ? md->n_env : 1;
     M.G = md->kind == BB_MODEL_GENOTYPE ? md->n_geno : 0;
     M.nn = md->n_neutral;
     M.nb = md->n_bc;
@@ -517,9 +521,10 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         cnt += (long long)T * M.B;
     }
     M.K += 2;
-    if (md->kind == BB_MODEL_MULTIENV) {
-        if (md->n_env < 1 || !md->env_idx) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "multienv needs n_env >= 1 and env_idx"); }
-        for (int t = 0; t < M.T[0]; ++t)
+    const bool has_env = md->kind == BB_MODEL_MULTIENV || md->kind == BB_MODEL_MULTIENV_REPLICATE;
+    if (has_env) {
+        if (md->n_env < 1 || !md->env_idx) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "multienv models need n_env >= 1 and env_idx"); }
+        for (int t = 0; t < M.Ttot; ++t)
             if (md->env_idx[t] < 0 || md->env_idx[t] >= md->n_env) { bb_destroy(h); return bb_fail(BB_ERR_INVALID, "env_idx[%d] out of range", t); }
     }
     if (md->kind == BB_MODEL_GENOTYPE) {
@@ -537,10 +542,11 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         add_block(h, "s_bc", BK_S, M.nb * M.E, &off);
         add_block(h, "logsigma_bc", BK_LS, M.nb * M.E, &off);
     } else {
-        add_block(h, "theta", BK_S, M.kind == BB_MODEL_GENOTYPE ? M.G : M.nb, &off);
-        add_block(h, "theta_tilde", BK_TT, M.nb * M.R, &off);
-        add_block(h, "logtau", BK_LT, M.nb * M.R, &off);
-        add_block(h, "logsigma_bc", BK_LS, M.nb * M.R, &off);
+        const long long E_ = M.kind == BB_MODEL_MULTIENV_REPLICATE ? M.E : 1;
+        add_block(h, "theta", BK_S, M.kind == BB_MODEL_GENOTYPE ? M.G : M.nb * E_, &off);
+        add_block(h, "theta_tilde", BK_TT, M.nb * M.R * E_, &off);
+        add_block(h, "logtau", BK_LT, M.nb * M.R * E_, &off);
+        add_block(h, "logsigma_bc", BK_LS, M.nb * M.R * E_, &off);
     }
     add_block(h, "loglambda", BK_L, n_l, &off);
     M.D = off;
@@ -578,10 +584,10 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(h2d(dcounts, c32.data(), (size_t)cnt * 4, h->stream));
     M.counts = dcounts;
 
-    if (md->kind == BB_MODEL_MULTIENV) {
+    if (has_env) {
         int* d = nullptr;
-        BB_TRY(dalloc(h, &d, (size_t)M.T[0]));
-        BB_TRY(h2d(d, md->env_idx, (size_t)M.T[0] * 4, h->stream));
+        BB_TRY(dalloc(h, &d, (size_t)M.Ttot));
+        BB_TRY(h2d(d, md->env_idx, (size_t)M.Ttot * 4, h->stream));
         M.env_idx = d;
     }
     if (md->kind == BB_MODEL_GENOTYPE) {
@@ -644,7 +650,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         const size_t lds_cap = (size_t)160 * 1024 / (size_t)bpc;
         int nthr = 0;
         for (;;) {
-            const int per_mutant = M.kind == 0 ? 2 : (M.kind == 1 ? 2 * M.E : (M.kind == 2 ? 3 : 1 + 3 * M.R));
+            const int per_mutant = M.kind == 0 ? 2 : (M.kind == 1 ? 2 * M.E : (M.kind == 2 ? 3 : (M.kind == 3 ? 1 + 3 * M.R : M.E * (1 + 3 * M.R))));
             const long long pairs = (long long)NB * (M.Ttot + per_mutant) / 2;   // one pair of latents per thread is the sweet spot
             nthr = pairs > 512 ? 1024 : (pairs > 256 ? 512 : 256);
             if ((ev = getenv("BB_TUNE_NTHR")) && atoi(ev) >= 64) nthr = atoi(ev) / 64 * 64;
@@ -797,7 +803,8 @@ static int launch_sample(bb_handle* h, const RunArgs& A) {
         case 0: bb_block_sample<0>(cx, h->M, h->S, A, h->NB); break;
         case 1: bb_block_sample<1>(cx, h->M, h->S, A, h->NB); break;
         case 2: bb_block_sample<2>(cx, h->M, h->S, A, h->NB); break;
-        default: bb_block_sample<3>(cx, h->M, h->S, A, h->NB);
+        case 3: bb_block_sample<3>(cx, h->M, h->S, A, h->NB); break;
+        default: bb_block_sample<4>(cx, h->M, h->S, A, h->NB);
         }
     });
 #else
@@ -812,7 +819,8 @@ static int launch_update(bb_handle* h, const RunArgs& A) {
         case 0: bb_block_update<0>(cx, h->M, h->S, A, h->NB); break;
         case 1: bb_block_update<1>(cx, h->M, h->S, A, h->NB); break;
         case 2: bb_block_update<2>(cx, h->M, h->S, A, h->NB); break;
-        default: bb_block_update<3>(cx, h->M, h->S, A, h->NB);
+        case 3: bb_block_update<3>(cx, h->M, h->S, A, h->NB); break;
+        default: bb_block_update<4>(cx, h->M, h->S, A, h->NB);
         }
     });
 #else

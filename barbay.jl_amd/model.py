@@ -8,6 +8,9 @@ src/vi.jl:172-178 -- that `vi.advi` hands to the HIP engine; no math happens her
     genotype_fitness_normal   src/model_fitness_normal_hierarchical_genotypes.jl:151-163
     replicate_fitness_normal  src/model_fitness_normal_hierarchical_replicates.jl:145-156 (3-D array)
                               and :407-418 (Vector{Matrix}: replicates with different time points)
+    multienv_replicate_fitness_normal
+                              src/model_multienv_fitness_normal_hierarchical_replicates.jl:158-170 (3-D array)
+                              and :449-461 (Vector{Matrix})
 
 Prior keywords accept the reference's spellings (`logσ_pop_prior`, `logλ_prior`, `logτ_prior`, ...)
 and ASCII aliases (`logsigma_pop_prior`, `loglambda_prior`, `logtau_prior`).  A prior is either the
@@ -60,7 +63,7 @@ def _prior(value, name: str) -> Tuple[np.ndarray, np.ndarray]:
 @dataclass
 class BayesModel:
     """A constructed model instance (the role of the DynamicPPL.Model at src/vi.jl:172)."""
-    kind: str                       # fitness | multienv | genotype | replicate
+    kind: str                       # fitness | multienv | genotype | replicate | multienv_replicate
     name: str
     counts: List[np.ndarray]        # per replicate, T_r x B
     totals: List[np.ndarray]
@@ -141,3 +144,34 @@ def replicate_fitness_normal(R, n_t, n_neutral: int, n_bc: int, **kwargs) -> Bay
         t = [np.ascontiguousarray(n_t[:, r]) for r in range(R.shape[2])]
     return BayesModel("replicate", "replicate_fitness_normal", c, t, int(n_neutral), int(n_bc),
                       priors=_split_kwargs(kwargs), ragged=ragged)
+
+
+def multienv_replicate_fitness_normal(R, n_t, n_neutral: int, n_bc: int, *, envs, **kwargs) -> BayesModel:
+    """model_multienv_fitness_normal_hierarchical_replicates.jl: R is T x B x n_rep with one `envs` list (:158-363)
+    or a list of T_r x B matrices with one env list per replicate (:449-687).  theta is n_env x n_bc (environment
+    fastest), theta_tilde / logtau / logsigma_bc are n_env x n_bc x n_rep; time step t of replicate r uses the
+    environment of t+1 (:339-352)."""
+    ragged = isinstance(R, (list, tuple))
+    if ragged:
+        c = [np.asarray(r, dtype=np.int64) for r in R]
+        t = [np.asarray(n, dtype=np.int64) for n in n_t]
+        per = [list(e) for e in envs]
+        if len(per) != len(c) or any(len(e) != len(tt) for e, tt in zip(per, t)):
+            raise BarBayError("Number of time points must match list of of environments for all replicates")   # :462-464
+    else:
+        R = np.asarray(R, dtype=np.int64)
+        n_t = np.asarray(n_t, dtype=np.int64)
+        if R.ndim != 3:
+            raise BarBayError("multienv_replicate_fitness_normal expects a T x B x n_rep array or a list of matrices")
+        if n_t.shape[0] != len(envs):
+            raise BarBayError("Number of time points must match list of of environments")                      # :172-174
+        c = [np.ascontiguousarray(R[:, :, r]) for r in range(R.shape[2])]
+        t = [np.ascontiguousarray(n_t[:, r]) for r in range(R.shape[2])]
+        per = [list(envs)] * R.shape[2]
+    flat, _ = _first_appearance_index(sum(per, []))         # indexin.(envs, Ref(unique(vcat(envs...)))) :466-472
+    idx, o = [], 0
+    for e in per:
+        idx.append(flat[o:o + len(e)])
+        o += len(e)
+    return BayesModel("multienv_replicate", "multienv_replicate_fitness_normal", c, t, int(n_neutral), int(n_bc),
+                      env_idx=idx, priors=_split_kwargs(kwargs), ragged=ragged)

@@ -34,10 +34,15 @@ def owned_indices(kind: str, layout: Dict[str, Tuple[int, int]], b_lo: int, b_hi
         idx += [layout["s_bc"][0] + me, layout["logsigma_bc"][0] + me]
     elif kind == "genotype":
         idx += [layout[k][0] + m for k in ("theta_tilde", "logtau", "logsigma_bc")]
-    else:
+    elif kind == "replicate":
         idx.append(layout["theta"][0] + m)
         for r in range(n_rep):
             idx += [layout[k][0] + r * n_bc + m for k in ("theta_tilde", "logtau", "logsigma_bc")]
+    else:   # multienv_replicate: theta[e, m]; tt / lt / ls [e, m, r], environment fastest
+        me = np.arange(m_lo * n_env, m_hi * n_env)
+        idx.append(layout["theta"][0] + me)
+        for r in range(n_rep):
+            idx += [layout[k][0] + r * n_bc * n_env + me for k in ("theta_tilde", "logtau", "logsigma_bc")]
     return np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64)
 
 

@@ -180,11 +180,16 @@ def advi_to_df(data: pd.DataFrame, dist, vars: Sequence[str], *, id_col="barcode
             if n_env == 1:
                 env[lo:hi] = "env1"
             elif "̲ₜ" in g:
-                env[lo:hi] = list(output.envs[1:])
-            elif g in ("θ̲⁽ᵐ⁾", "s̲⁽ᵐ⁾", "logσ̲⁽ᵐ⁾"):
+                # the reference assigns `output.envs[2:end]` (:1179), which only fits one replicate; with replicates
+                # the block holds (T_r - 1) entries per replicate, so the per-replicate lists are concatenated
+                per = output.envs if (output.envs and isinstance(output.envs[0], (list, tuple))) else [output.envs] * max(n_rep, 1)
+                env[lo:hi] = sum([list(e[1:]) for e in per], [])
+            elif g != "logΛ̲̲":
                 # the reference fills θ̲⁽ᵐ⁾ only and leaves the other blocks #undef (:1182-1184); the
                 # per-environment blocks are stored env-fastest (model_multienv_fitness_normal.jl:271-272)
-                env[lo:hi] = list(dict.fromkeys(output.envs)) * n_bc
+                flat = sum(output.envs, []) if (output.envs and isinstance(output.envs[0], (list, tuple))) else list(output.envs)
+                uniq = list(dict.fromkeys(flat))
+                env[lo:hi] = uniq * ((hi - lo) // len(uniq))
         df[env_col] = env
     ids = np.empty(len(df), dtype=object)                                          # add_barcode_info! :1192-1279
     for (lo, hi), g in zip(var_range, var_groups):

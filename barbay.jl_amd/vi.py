@@ -58,7 +58,7 @@ def make_engine(bayes_model: BayesModel, advi: ADVI, opt, seed: int = 0, device:
     return Engine(bayes_model.kind, bayes_model.counts, bayes_model.n_neutral, bayes_model.n_bc,
                   totals=bayes_model.totals, env_idx=bayes_model.env_idx, geno_idx=bayes_model.geno_idx, priors=pri,
                   samples_per_step=advi.samples_per_step, seed=seed, device=device,
-                  ragged_method=bayes_model.ragged, **okw, **engine_kwargs)
+                  ragged_method=bayes_model.ragged and bayes_model.kind == "replicate", **okw, **engine_kwargs)
 
 
 def vi(bayes_model: BayesModel, advi: ADVI, optimizer=None, seed: int = 0, device: int = 0, **engine_kwargs):

@@ -40,6 +40,9 @@ extern "C" {
 #define BB_MODEL_REPLICATE 3  /* replicate_fitness_normal  src/model_fitness_normal_hierarchical_replicates.jl:145-332 (3-D)
                                  and :407-638 (ragged); equal n_time[] == the 3-D method */
 
+#define BB_MODEL_MULTIENV_REPLICATE 4 /* multienv_replicate_fitness_normal
+                                 src/model_multienv_fitness_normal_hierarchical_replicates.jl:158-363 (3-D), :449-687 (ragged) */
+
 /* bb_model_desc.flags */
 #define BB_FLAG_RAGGED_METHOD 1 /* BB_MODEL_REPLICATE called as the reference's Vector{Matrix} method
                                   (src/model_fitness_normal_hierarchical_replicates.jl:407-638): its neutral
@@ -65,14 +68,16 @@ typedef struct bb_prior {
  * in the layout src/utils.jl:48-61 (DataArrays) hands over. */
 typedef struct bb_model_desc {
     int32_t kind;            /* BB_MODEL_*                                                */
-    int32_t n_rep;           /* replicates (1 unless BB_MODEL_REPLICATE)                  */
+    int32_t n_rep;           /* replicates (1 unless BB_MODEL_REPLICATE / _MULTIENV_REPLICATE) */
     int64_t n_neutral;       /* neutral barcodes: columns 0..n_neutral-1 (utils.jl:431)   */
     int64_t n_bc;            /* mutant barcodes                                           */
     const int32_t* n_time;   /* [n_rep] time points per replicate                         */
     const int64_t* counts;   /* replicate-major; each T_r x B column-major (t fastest)    */
     const int64_t* totals;   /* replicate-major; [T_r] = row sums of counts               */
     int32_t n_env;           /* BB_MODEL_MULTIENV: number of distinct environments        */
-    const int32_t* env_idx;  /* [T] 0-based env of each time point (indexin(envs, unique))*/
+    const int32_t* env_idx;  /* [sum_r T_r] 0-based env of each time point, replicate-major
+                                (indexin(envs, unique(envs)); the 3-D multienv_replicate method
+                                repeats its one env list per replicate)                   */
     int32_t n_geno;          /* BB_MODEL_GENOTYPE: number of distinct genotypes           */
     const int32_t* geno_idx; /* [n_bc] 0-based genotype of each mutant                    */
     bb_prior s_pop_prior;        /* default [0,2] */

@@ -100,6 +100,16 @@ def synthetic(kind: str, B: int, T, n_rep: int = 1, n_env: int = 1, n_geno: int 
     if kind == "multienv":
         e = list(range(n_env)) + list(g.integers(0, n_env, max(0, Ts[0] - n_env)))
         kw["env_idx"] = _first_idx(e[:Ts[0]])
+    if kind == "multienv_replicate":
+        per = []
+        for r in range(len(Ts)):
+            e = (list(range(n_env)) if r == 0 else []) + list(g.integers(0, n_env, Ts[r]))
+            per.append(e[:Ts[r]])
+        flat = _first_idx(sum(per, []))           # indexin.(envs, Ref(unique(vcat(envs...))))
+        kw["env_idx"], o = [], 0
+        for r in range(len(Ts)):
+            kw["env_idx"].append(flat[o:o + Ts[r]])
+            o += Ts[r]
     if kind == "genotype":
         kw["geno_idx"] = _first_idx(list(g.integers(0, max(1, n_geno), nb)))
     return ModelSpec(kind=kind, counts=counts, totals=[c.sum(axis=1) for c in counts], n_neutral=nn,

@@ -238,11 +238,62 @@ def logjoint_replicate(z: torch.Tensor, sp: ModelSpec, ragged_quirk: bool = Fals
     return lp
 
 
+def logjoint_multienv_replicate(z: torch.Tensor, sp: ModelSpec) -> torch.Tensor:
+    """model_multienv_fitness_normal_hierarchical_replicates.jl:172-362 (3-D method) and :462-686 (ragged method),
+    transcribed as one per-replicate loop in the ragged method's shape (rep_ranges / time_ranges :474-491); with
+    equal T_r and a common env list the two methods define the same density (the ragged method's neutral term uses
+    the outer `repeat(s_t[range], n_neutral)`, :653-667, i.e. no ordering quirk here)."""
+    off, pr = sp.offsets(), sp.priors
+    B, nn, nb, Rn, E = sp.B, sp.n_neutral, sp.n_bc, sp.n_rep, sp.n_env
+    Ts = sp.n_time
+    s_t = z[slice(*off["s_pop"])]
+    lsig_t = z[slice(*off["logsigma_pop"])]
+    theta = z[slice(*off["theta"])]
+    theta_t = z[slice(*off["theta_tilde"])]
+    ltau = z[slice(*off["logtau"])]
+    lsig_m = z[slice(*off["logsigma_bc"])]
+    logL = z[slice(*off["loglambda"])]
+    lp = _prior(s_t, *pr["s_pop_prior"])                       # :191-200 / :498-507
+    lp = lp + _prior(lsig_t, *pr["logsigma_pop_prior"])        # :203-213 / :510-520
+    lp = lp + _prior(theta, *pr["s_bc_prior"])                 # :218-227 / :525-534
+    lp = lp + _prior(theta_t, 0.0, 1.0)                        # :230-232 / :537-539
+    lp = lp + _prior(ltau, *pr["logtau_prior"])                # :235-238 / :542-545
+    s_m = theta.repeat(Rn) + torch.exp(ltau) * theta_t         # :241 / :548
+    lp = lp + _prior(lsig_m, *pr["logsigma_bc_prior"])         # :244-254 / :551-561
+    lp = lp + _prior(logL, *pr["loglambda_prior"])             # :258-270 / :565-577
+    s_m3 = _jl_reshape(s_m, E, nb, Rn)                         # :311 / :606   n_env x n_bc x n_rep
+    lsig_m3 = _jl_reshape(lsig_m, E, nb, Rn)                   # :312 / :607
+    expL = torch.exp(logL)
+    ro, to = 0, 0
+    for r in range(Rn):
+        T = Ts[r]
+        env_idx = torch.as_tensor(sp.env_idx[r])
+        Lam = _jl_reshape(expL[ro:ro + T * B], T, B)           # :276 / :584-587
+        F = Lam / Lam.sum(dim=1, keepdim=True)                 # :279 / :590
+        logG = torch.log(F[1:, :] / F[:-1, :])                 # :282 / :593
+        logG_n = _jl_vec(logG[:, :nn])
+        logG_m = _jl_vec(logG[:, nn:nn + nb])
+        Rr = torch.as_tensor(sp.counts[r], dtype=F64)
+        n_t = torch.as_tensor(sp.totals[r], dtype=F64)
+        lp = lp + _obs_terms(Lam, Rr, n_t)                     # :291-306 / :612-637
+        st_r = s_t[to:to + T - 1]
+        sg_r = lsig_t[to:to + T - 1]
+        lp = lp + mvnormal_diag_logpdf(logG_n, (-st_r).repeat(nn), (torch.exp(sg_r) ** 2).repeat(nn))   # :322-334 / :647-668
+        lp = lp + mvnormal_diag_logpdf(                        # :339-352 / :670-682
+            logG_m,
+            _jl_vec(s_m3[env_idx[1:], :, r]) - st_r.repeat(nb),
+            _jl_vec(torch.exp(lsig_m3[env_idx[1:], :, r])) ** 2)
+        ro += T * B
+        to += T - 1
+    return lp
+
+
 _LOGJOINT = {
     "fitness": logjoint_fitness,
     "multienv": logjoint_multienv,
     "genotype": logjoint_genotype,
     "replicate": logjoint_replicate,
+    "multienv_replicate": logjoint_multienv_replicate,
 }
 
 

@@ -8,6 +8,9 @@ source order; Julia arrays are column-major.  Block orders follow
 * genotype_fitness_normal   /root/reference/src/model_fitness_normal_hierarchical_genotypes.jl:181-258
 * replicate_fitness_normal  /root/reference/src/model_fitness_normal_hierarchical_replicates.jl:164-243 (3-D)
                             and :451-530 (ragged Vector{Matrix})
+* multienv_replicate_fitness_normal
+                            /root/reference/src/model_multienv_fitness_normal_hierarchical_replicates.jl:190-288 (3-D)
+                            and :497-581 (ragged)
 """
 from __future__ import annotations
 
@@ -16,7 +19,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-KINDS = ("fitness", "multienv", "genotype", "replicate")
+KINDS = ("fitness", "multienv", "genotype", "replicate", "multienv_replicate")
 
 # reference defaults: model_fitness_normal.jl:125-129, ..._genotypes.jl:162
 DEFAULT_PRIORS = {
@@ -57,7 +60,7 @@ class ModelSpec:
         for c, t in zip(self.counts, self.totals):
             assert c.ndim == 2 and c.shape[1] == self.n_neutral + self.n_bc
             assert t.shape == (c.shape[0],)
-        if self.kind != "replicate":
+        if self.kind not in ("replicate", "multienv_replicate"):
             assert len(self.counts) == 1
         p = dict(DEFAULT_PRIORS)
         p.update(self.priors)
@@ -65,6 +68,12 @@ class ModelSpec:
         if self.kind == "multienv":
             assert self.env_idx is not None and len(self.env_idx) == self.n_time[0]
             self.env_idx = np.asarray(self.env_idx, dtype=np.int64)
+        if self.kind == "multienv_replicate":
+            # env_idx: one 0-based index list per replicate (first appearance over the concatenation,
+            # `indexin.(envs, Ref(unique(vcat(envs...))))`, model_multienv_..._replicates.jl:466-472)
+            assert self.env_idx is not None and len(self.env_idx) == len(self.counts)
+            self.env_idx = [np.asarray(e, dtype=np.int64) for e in self.env_idx]
+            assert all(len(e) == t for e, t in zip(self.env_idx, self.n_time))
         if self.kind == "genotype":
             assert self.geno_idx is not None and len(self.geno_idx) == self.n_bc
             self.geno_idx = np.asarray(self.geno_idx, dtype=np.int64)
@@ -83,7 +92,11 @@ class ModelSpec:
 
     @property
     def n_env(self) -> int:
-        return int(self.env_idx.max()) + 1 if self.env_idx is not None else 1
+        if self.env_idx is None:
+            return 1
+        if self.kind == "multienv_replicate":
+            return int(max(e.max() for e in self.env_idx)) + 1
+        return int(self.env_idx.max()) + 1
 
     @property
     def n_geno(self) -> int:
@@ -107,6 +120,11 @@ class ModelSpec:
             return [("s_pop", nt1, "s_pop_prior"), ("logsigma_pop", nt1, "logsigma_pop_prior"),
                     ("theta", G, "s_bc_prior"), ("theta_tilde", nb, "_std_normal"),
                     ("logtau", nb, "logtau_prior"), ("logsigma_bc", nb, "logsigma_bc_prior"),
+                    ("loglambda", nl, "loglambda_prior")]
+        if self.kind == "multienv_replicate":
+            return [("s_pop", nt1, "s_pop_prior"), ("logsigma_pop", nt1, "logsigma_pop_prior"),
+                    ("theta", E * nb, "s_bc_prior"), ("theta_tilde", E * nb * R, "_std_normal"),
+                    ("logtau", E * nb * R, "logtau_prior"), ("logsigma_bc", E * nb * R, "logsigma_bc_prior"),
                     ("loglambda", nl, "loglambda_prior")]
         return [("s_pop", nt1, "s_pop_prior"), ("logsigma_pop", nt1, "logsigma_pop_prior"),
                 ("theta", nb, "s_bc_prior"), ("theta_tilde", nb * R, "_std_normal"),

@@ -21,6 +21,8 @@ SYNTH = {
     "genotype": ("genotype", dict(B=800, T=6, n_geno=17, n_neutral=256)),
     "replicate_ragged": ("replicate", dict(B=530, T=[5, 7, 4], n_rep=3, n_neutral=20)),
     "replicate_3d": ("replicate", dict(B=300, T=6, n_rep=2, n_neutral=1)),
+    "multienv_replicate": ("multienv_replicate", dict(B=420, T=[5, 7, 4], n_rep=3, n_env=3, n_neutral=23)),
+    "multienv_replicate_3d": ("multienv_replicate", dict(B=150, T=5, n_rep=2, n_env=2, n_neutral=9)),
 }
 
 

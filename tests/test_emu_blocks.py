@@ -20,7 +20,7 @@ def test_normals(emu_lib):
     c.case_normals(emu_lib)
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
 @pytest.mark.parametrize("opt", ["TruncatedADAGrad", "DecayedADAGrad"])
 @pytest.mark.parametrize("S", [1, 2])
 def test_trajectory_exact(emu_lib, name, opt, S):
@@ -36,7 +36,7 @@ def test_matrix_priors(emu_lib):
     c.case_matrix_priors(emu_lib)
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged", "multienv_replicate"])
 def test_sharded_split_phase(emu_lib, name):
     c.case_sharded_split_phase(emu_lib, name)
 
@@ -56,7 +56,8 @@ def test_launch_geometries(emu_lib, monkeypatch, nb, nthr):
     c.case_trajectory_exact(emu_lib, "genotype", "DecayedADAGrad", 1)
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d", "multienv_replicate",
+                                  "multienv_replicate_3d"])
 def test_persistent_equals_two_kernel(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name)
 

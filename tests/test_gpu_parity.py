@@ -22,7 +22,7 @@ def test_normals(hip_lib):
     c.case_normals(hip_lib)
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
 @pytest.mark.parametrize("opt", ["TruncatedADAGrad", "DecayedADAGrad"])
 @pytest.mark.parametrize("S", [1, 2])
 def test_trajectory_exact(hip_lib, name, opt, S):
@@ -39,7 +39,7 @@ def test_matrix_priors(hip_lib):
     c.case_matrix_priors(hip_lib)
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged", "multienv_replicate"])
 def test_sharded_split_phase(hip_lib, name):
     c.case_sharded_split_phase(hip_lib, name)
 
@@ -111,7 +111,8 @@ def test_rccl_path_single_rank(hip_lib, monkeypatch):
     assert np.abs(got[0] - ref[0]).max() < 1e-9 and np.abs(got[1] - ref[1]).max() < 1e-9
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d", "multienv_replicate",
+                                  "multienv_replicate_3d"])
 def test_persistent_equals_two_kernel(hip_lib, name):
     c.case_persistent_equals_two_kernel(hip_lib, name)
 

@@ -79,3 +79,16 @@ def test_long_run_matches_cpu_port_and_brackets_truth():
     fit = r[r.vartype == "bc_fitness"].set_index("id")
     truth = data[~data.neutral].drop_duplicates("barcode").set_index("barcode")["fitness"].loc[fit.index]
     assert (np.abs(fit["mean"] - truth) < 3 * fit["std"]).all()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_multienv_replicate_advi(ragged):
+    """§8f rank 1 end to end: BarBay.model.multienv_replicate_fitness_normal needs rep_col and env_col."""
+    from test_host_surface import _tidy_rep_env
+    df = _tidy_rep_env(ragged)
+    r = bb.vi.advi(data=df, model=bb.model.multienv_replicate_fitness_normal, rep_col="rep", env_col="env",
+                   advi=bb.vi.ADVI(1, 30), verbose=False)
+    assert {"bc_hyperfitness", "bc_noncenter", "bc_deviations", "bc_fitness"} <= set(r.vartype)
+    assert np.isfinite(r["mean"]).all() and (r["std"] > 0).all()
+    with pytest.raises(bb.BarBayError, match="env_col"):
+        bb.vi.advi(data=df, model=bb.model.multienv_replicate_fitness_normal, rep_col="rep", advi=bb.vi.ADVI(1, 1))

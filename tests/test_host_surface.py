@@ -118,3 +118,49 @@ def test_advi_argument_errors_without_gpu():
         bb.vi.advi(data=df, model=bb.model.replicate_fitness_normal, advi=bb.vi.ADVI(1, 1))
     with pytest.raises(bb.BarBayError, match="env_col"):
         bb.vi.advi(data=df, model=bb.model.multienv_fitness_normal, advi=bb.vi.ADVI(1, 1))
+
+
+def _tidy_rep_env(ragged=False, seed=0):
+    g = np.random.default_rng(seed)
+    rows = []
+    envs = {"R1": ["a", "a", "b", "c", "b"], "R2": ["a", "a", "b", "c", "b"] if not ragged else ["a", "c", "b", "b"]}
+    for rep, ev in envs.items():
+        for bc in [f"neutral{i:03d}" for i in range(3)] + [f"mut{i:03d}" for i in range(6)]:
+            for t, e in enumerate(ev, start=1):
+                rows.append(dict(time=t, env=e, barcode=bc, count=int(g.integers(200, 5000)), neutral=bc.startswith("neutral"), rep=rep))
+    return pd.DataFrame(rows)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_multienv_replicate_surface(ragged):
+    """§8f rank 1: multienv_replicate_fitness_normal (3-D and ragged calls) through data_to_arrays -> model ->
+    labels, no engine."""
+    df = _tidy_rep_env(ragged)
+    d = bb.utils.data_to_arrays(df, rep_col="rep", env_col="env")
+    assert d.n_rep == 2 and d.n_env == 3
+    bm = bb.model.multienv_replicate_fitness_normal(d.bc_count, d.bc_total, d.n_neutral, d.n_bc, envs=d.envs)
+    assert bm.kind == "multienv_replicate" and bm.ragged == ragged and len(bm.env_idx) == 2
+    assert [len(e) for e in bm.env_idx] == [c.shape[0] for c in bm.counts]
+    assert bm.env_idx[0].tolist() == [0, 0, 1, 2, 1]
+    if ragged:
+        assert bm.env_idx[1].tolist() == [0, 2, 1, 1]
+    E, nb, R = 3, 6, 2
+    nt1 = sum(c.shape[0] - 1 for c in bm.counts)
+    nl = sum(c.size for c in bm.counts)
+    sizes = [nt1, nt1, E * nb, E * nb * R, E * nb * R, E * nb * R, nl]
+    ranges, o = [], 0
+    for n in sizes:
+        ranges.append((o, o + n))
+        o += n
+    q = SimpleNamespace(dist=SimpleNamespace(m=np.zeros(o), σ=np.ones(o)), transform=SimpleNamespace(ranges_out=ranges))
+    names = []
+    for sym, (lo, hi) in zip(bm.var_symbols(), ranges):
+        names += [f"{sym}[{i}]" for i in range(1, hi - lo + 1)]
+    out = bb.utils.advi_to_df(df, q, names, rep_col="rep", env_col="env", n_samples=50, rng=np.random.default_rng(0))
+    base = out.iloc[:o]
+    th = base[base.vartype == "bc_hyperfitness"]
+    assert list(th["env"][:3]) == ["a", "b", "c"] and list(th["id"][:3]) == [d.bc_ids[0]] * 3
+    assert len(base[base.vartype == "pop_mean_fitness"]["env"]) == nt1
+    assert (out.iloc[o:].vartype == "bc_fitness").all() and len(out) == o + E * nb * R
+    with pytest.raises(bb.BarBayError, match="environments"):
+        bb.model.multienv_replicate_fitness_normal(d.bc_count, d.bc_total, d.n_neutral, d.n_bc, envs=["a"])
