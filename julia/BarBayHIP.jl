@@ -70,7 +70,7 @@ struct Transform; ranges_out::Vector{UnitRange{Int}}; end
 struct Posterior; dist::Dist; transform::Transform; end
 
 const KIND = Dict("fitness_normal" => 0, "multienv_fitness_normal" => 1, "genotype_fitness_normal" => 2,
-                  "replicate_fitness_normal" => 3)
+                  "replicate_fitness_normal" => 3, "multienv_replicate_fitness_normal" => 4)
 
 # prior kwarg (`VecOrMat{Float64}`) -> (mean, std) vectors kept alive by the caller
 _prior_arrays(p::Vector{Float64}) = ([p[1]], [p[2]])
@@ -92,7 +92,10 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
     n_time = Int32[size(m, 1) for m in mats]
     counts = reduce(vcat, vec.(mats))              # column-major T x B, t fastest: passed as is
     totals = reduce(vcat, tots)
-    env_idx = envs === nothing ? Int32[] : Int32.(indexin(envs, unique(envs)) .- 1)
+    # env list per replicate, replicate-major (the 3-D multienv_replicate method repeats its one list per replicate)
+    envs_rep = envs === nothing ? nothing : (envs isa Vector{<:Vector} ? envs : [envs for _ in mats])
+    env_flat = envs_rep === nothing ? nothing : reduce(vcat, envs_rep)
+    env_idx = env_flat === nothing ? Int32[] : Int32.(indexin(env_flat, unique(env_flat)) .- 1)
     geno_idx = genotypes === nothing ? Int32[] : Int32.(indexin(genotypes, unique(genotypes)) .- 1)
     pa = Dict(k => _prior_arrays(v) for (k, v) in priors)
     pr(k) = haskey(pa, k) ? bb_prior(pointer(pa[k][1]), pointer(pa[k][2]), length(pa[k][1])) : bb_prior()
