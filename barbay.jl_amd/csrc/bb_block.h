@@ -124,7 +124,7 @@ BB_DEV void bb_prior_of(const DevModel& M, int blk, long long j, double* mean, d
 // LDS carve-up (offsets in doubles) for a tile of NB barcodes worked by nthr threads.
 // ------------------------------------------------------------------------------------------------
 struct BBLds {
-    int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg, zgl;
+    int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg, zgl, lam;
     int total;
 };
 
@@ -163,6 +163,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.elbt = o; o += Ttot;
     L.seg = o;  o += 5 * (BB_MAX_SEG + 1);
     L.zgl = o;  o += 2 * nt1;
+    L.lam = o;  o += NB * Ttot;   // exp(loglambda sample) of the tile, written by the moments pass
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -514,6 +515,7 @@ BB_DEV void bb_pass_moments(BBCtx& cx, const DevModel& M, const DevState& S, con
                 for (int bl = blq; bl < t.nbt; bl += bstride) {
                     const double z = zl[bl * T + tt];
                     const double lam = bb_exp(z);
+                    lds[L.lam + NB * M.tcum[r] + bl * T + tt] = lam;
                     aS += lam;
                     if (we) el += (double)M.counts[M.cnt_off[r] + (t.b0 + bl) * T + tt] * z - lam;
                     if (tt < T - 1) {
@@ -853,7 +855,7 @@ BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState
 }
 
 // Likelihood part of d logjoint / d z for latent j of segment s (z = its sample), gathered from the LDS tables.
-template <int KIND>
+template <int KIND, bool LAM_IN_LDS>
 BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, const BBTile& t, int NB, const BBSeg& s,
                       long long j, double z) {
     const int ns = t.nshift;
@@ -864,7 +866,7 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
         const double* res = lds + L.res + NB * (tc - r);
         const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
         const bool mut = bl >= ns;
-        const double lam = bb_exp(z);
+        const double lam = LAM_IN_LDS ? lds[L.lam + NB * tc + j] : bb_exp(z);   // the resident launch keeps the moments pass's table
         const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
         double g = cnt - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
         const bool qk = KIND == 3 && M.quirk && !mut;
@@ -947,7 +949,7 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
     // pass G: gather each latent's likelihood gradient from the LDS tables and update it
     BB_PASS(cx, tid) {
         const BBSlot wslot = bb_slot_of(A, step);
-        auto glik = [&](const BBSeg& s, long long j, double z) -> double { return bb_glik<KIND>(lds, M, L, t, NB, s, j, z); };
+        auto glik = [&](const BBSeg& s, long long j, double z) -> double { return bb_glik<KIND, false>(lds, M, L, t, NB, s, j, z); };
         bb_for_pairs(cx, tid, sg, li[0], [&](const BBSeg& s, long long i0, bool a0, bool a1) {
             double z0 = 0.0, z1 = 0.0;
             if (a0 && a1) { const bb_d2 z = *(const bb_d2*)(S.zsv + i0); z0 = z.x; z1 = z.y; }

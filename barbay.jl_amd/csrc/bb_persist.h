@@ -23,6 +23,8 @@ struct BBPst {
     bb_d2 mu[P], om[P], am[P], ao[P];   // variational parameters and optimiser accumulators of P pairs
     bb_d2 a[P], h[P];                   // current draw: eps*sigmoid(omega), sigmoid/softplus (z itself stays staged in LDS)
     bb_d2 hm[P], ho[P];                 // this step's TruncatedADAGrad window slot, fetched while the exchange is in flight
+    long long i0[P];                    // first latent of each pair
+    int meta[P];                        // segment index | a0 << 8 | a1 << 9 | valid << 10
 };
 
 #ifdef BB_EMU
@@ -42,6 +44,19 @@ BB_DEV BBPair bb_pair_of(const BBSeg* sg, int nseg, int p) {
     q.i0 = 2 * ((q.s.lo >> 1) + (p - q.s.pbeg));
     q.a0 = q.valid && q.i0 >= q.s.lo;
     q.a1 = q.valid && q.i0 + 1 < q.s.hi;
+    return q;
+}
+
+// the pair a thread owns never changes during a launch: found once, rebuilt from two registers afterwards
+template <int P>
+BB_DEV BBPair bb_pair_cached(const BBSeg* sg, const BBPst<P>& st, int k) {
+    BBPair q;
+    const int m = st.meta[k];
+    q.s = sg[m & 255];
+    q.i0 = st.i0[k];
+    q.a0 = (m >> 8) & 1;
+    q.a1 = (m >> 9) & 1;
+    q.valid = (m >> 10) & 1;
     return q;
 }
 
@@ -72,6 +87,12 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
+            {
+                int si = 0;
+                while (si + 1 < li[0] && q.valid && tid + k * cx.nthr >= sg[si + 1].pbeg) ++si;
+                st.i0[k] = q.i0;
+                st.meta[k] = si | ((int)q.a0 << 8) | ((int)q.a1 << 9) | ((int)q.valid << 10);
+            }
             st.mu[k] = bb_load_pair(S.mu, q.i0, q.a0, q.a1);
             st.om[k] = bb_load_pair(S.om, q.i0, q.a0, q.a1);
             st.am[k] = bb_load_pair(S.acc_mu, q.i0, q.a0, q.a1);
@@ -101,7 +122,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
         BBPst<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
+            const BBPair q = bb_pair_cached(sg, st, k);
             if (!q.valid) continue;
             double e0, e1, sp0, sg0, sp1, sg1;
             bb_normal_pair(A.seed, (unsigned long long)(q.i0 >> 1), (unsigned)step, 0u, &e0, &e1);
@@ -147,7 +168,7 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
             const double* hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
+                const BBPair q = bb_pair_cached(sg, st, k);
                 st.hm[k] = bb_load_pair(hs_m, q.i0, q.a0, q.a1);
                 st.ho[k] = bb_load_pair(hs_o, q.i0, q.a0, q.a1);
             }
@@ -299,7 +320,7 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             if (k == 0) BB_STAMP_W(cx, S, 29);
-            const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
+            const BBPair q = bb_pair_cached(sg, st, k);
             if (!q.valid) continue;
             const long long blo = M.blk_lo[q.s.blk];
             // the draw is still staged in LDS (tile latents) / came back with the totals (replicated global latents)
@@ -308,12 +329,12 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             if (q.a0) {
                 const double z0 = zsrc[q.i0 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 - blo, &pm, &iv);
-                g0 = bb_glik<KIND>(lds, M, L, t, NB, q.s, q.i0 - q.s.lo, z0) - (z0 - pm) * iv;
+                g0 = bb_glik<KIND, true>(lds, M, L, t, NB, q.s, q.i0 - q.s.lo, z0) - (z0 - pm) * iv;
             }
             if (q.a1) {
                 const double z1 = zsrc[q.i0 + 1 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 + 1 - blo, &pm, &iv);
-                g1 = bb_glik<KIND>(lds, M, L, t, NB, q.s, q.i0 + 1 - q.s.lo, z1) - (z1 - pm) * iv;
+                g1 = bb_glik<KIND, true>(lds, M, L, t, NB, q.s, q.i0 + 1 - q.s.lo, z1) - (z1 - pm) * iv;
             }
             if (k == 0) BB_STAMP_W(cx, S, 30);
             const double go0 = fma(g0, st.a[k].x, st.h[k].x), go1 = fma(g1, st.a[k].y, st.h[k].y);
@@ -348,7 +369,7 @@ BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const 
         BBPst<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const BBPair q = bb_pair_of(sg, li[0], tid + k * cx.nthr);
+            const BBPair q = bb_pair_cached(sg, st, k);
             if (!q.valid) continue;
             bb_store_pair(S.mu, q.i0, q.a0, q.a1, st.mu[k]);
             bb_store_pair(S.om, q.i0, q.a0, q.a1, st.om[k]);
