@@ -778,20 +778,17 @@ BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, 
         }
     }
     BB_SYNC(cx);
-    BB_PASS(cx, tid) {
-        for (int j = tid; j < M.Ttot; j += cx.nthr) {
-            int r = 0;
-            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
-            const int tt = j - M.tcum[r];
-            lds[L.GG + j] = (tt > 0 ? lds[L.Dt + j - 1] : 0.0) - lds[L.Dt + j];   // Dt == 0 at tt == T-1
+    // G_t = D_{t-1} - D_t is formed where it is used (bb_glik) from the D table (D == 0 at t == T-1): no third pass
+    if (A.with_elbo) {
+        BB_PASS(cx, tid) {
+            if (tid < M.R) {
+                double e = 0.0;
+                for (int tt = 0; tt < M.T[tid] - 1; ++tt) e += lds[L.elbt + M.tcum[tid] + tt];
+                lds[L.misc + 16 + tid] = e;
+            }
         }
-        if (tid < M.R) {
-            double e = 0.0;
-            for (int tt = 0; tt < M.T[tid] - 1; ++tt) e += lds[L.elbt + M.tcum[tid] + tt];
-            lds[L.misc + 16 + tid] = e;
-        }
+        BB_SYNC(cx);
     }
-    BB_SYNC(cx);
 }
 
 // Sum the moment rows and finish everything that depends on them.
@@ -868,7 +865,8 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
         const bool mut = bl >= ns;
         const double lam = LAM_IN_LDS ? lds[L.lam + NB * tc + j] : bb_exp(z);   // the resident launch keeps the moments pass's table
         const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
-        double g = cnt - lam + lam * lds[L.invS + tc + tt] * lds[L.GG + tc + tt];
+        const double Gt = (tt > 0 ? lds[L.Dt + tc + tt - 1] : 0.0) - lds[L.Dt + tc + tt];
+        double g = cnt - lam + lam * lds[L.invS + tc + tt] * Gt;
         const bool qk = KIND == 3 && M.quirk && !mut;
         if (tt < T1) {
             const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)]
