@@ -654,6 +654,18 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
     BB_STAMP(cx, S, 6);
 }
 
+// A finished total: store it; the S_t rows also yield 1/S_t and L_t = log S_t on the spot (saves a pass + barrier).
+BB_DEV void bb_put_total(const DevModel& M, const BBLds& L, double* lds, int k, double s) {
+    lds[L.wk + k] = s;
+    for (int r = 0; r < M.R; ++r) {
+        const int tt = k - M.kq[r];
+        if (tt >= 0 && tt < M.T[r]) {
+            lds[L.invS + M.tcum[r] + tt] = bb_rcp(s);
+            lds[L.Lt + M.tcum[r] + tt] = bb_log(s);
+        }
+    }
+}
+
 // Fixed-order sum of the moment rows into lds[L.wk]; the sampled global latents into lds[L.zgl].
 template <bool COH>
 BB_DEV void bb_finalize_sum(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, const double* zg) {
@@ -682,7 +694,7 @@ BB_DEV void bb_finalize_sum(BBCtx& cx, const DevModel& M, const DevState& S, con
             for (int k = tid; k < M.K; k += cx.nthr) {
                 double s = 0.0;
                 for (int c = 0; c < 16; ++c) s += tmp[k * 16 + c];
-                lds[L.wk + k] = s;
+                bb_put_total(M, L, lds, k, s);
             }
         }
     } else {             // few rows (totals, or the 8 group rows of the persistent launch): one batch per thread
@@ -694,7 +706,7 @@ BB_DEV void bb_finalize_sum(BBCtx& cx, const DevModel& M, const DevState& S, con
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s += v[i];
-                lds[L.wk + k] = s;
+                bb_put_total(M, L, lds, k, s);
             }
             for (int j = tid; j < 2 * M.nt1; j += cx.nthr) lds[L.zgl + j] = bb_ld<COH>(zg + j);
         }
@@ -707,18 +719,7 @@ template <int KIND>
 BB_DEV void bb_finalize_finish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L) {
     double* lds = cx.lds;
     BB_STAMP(cx, S, 9);
-    // everything that depends on the totals, one (replicate, time) item per thread
-    BB_PASS(cx, tid) {
-        for (int j = tid; j < M.Ttot; j += cx.nthr) {
-            int r = 0;
-            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
-            const int tt = j - M.tcum[r];
-            const double St = lds[L.wk + M.kq[r] + tt];
-            lds[L.invS + j] = bb_rcp(St);
-            lds[L.Lt + j] = bb_log(St);
-        }
-    }
-    BB_SYNC(cx);
+    // (1/S_t and L_t were written together with the totals, bb_put_total) one (replicate, time) item per thread
     BB_PASS(cx, tid) {
         for (int j = tid; j < M.Ttot; j += cx.nthr) {
             int r = 0;

@@ -287,7 +287,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += v[g];
-            if (k < M.K) lds[L.wk + k] = s;
+            if (k < M.K) bb_put_total(M, L, lds, k, s);
             else lds[L.zgl + (k - M.K)] = s;
         }
     }
