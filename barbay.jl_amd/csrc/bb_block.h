@@ -134,7 +134,7 @@ static inline
 #ifndef BB_EMU
 __host__ __device__
 #endif
-BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, int nthr) {
+BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, int nthr, int with_lam = 0) {
     BBLds L;
     int X = (kind == 1) ? E : (kind == 4 ? E * R : R);
     int o = 0;
@@ -163,7 +163,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.elbt = o; o += Ttot;
     L.seg = o;  o += 5 * (BB_MAX_SEG + 1);
     L.zgl = o;  o += 2 * nt1;
-    L.lam = o;  o += NB * Ttot;   // exp(loglambda sample) of the tile, written by the moments pass
+    L.lam = o;  o += with_lam ? NB * Ttot : 0;   // exp(loglambda sample) of the tile (resident launch only)
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -498,7 +498,7 @@ BB_DEV double bb_effective_tables(BBCtx& cx, int tid, const DevModel& M, const D
 
 // pass M: per replicate, every (barcode, time) element contributes to the moments of its time; the
 // tile's column sums land in lds[L.wk + row].  `we` also accumulates the Poisson ELBO terms.
-template <int KIND>
+template <int KIND, bool KEEP_LAM = false>
 BB_DEV void bb_pass_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, const BBTile& t, int NB, bool we) {
     double* lds = cx.lds;
     const int X = bb_xdim<KIND>(M);
@@ -515,7 +515,7 @@ BB_DEV void bb_pass_moments(BBCtx& cx, const DevModel& M, const DevState& S, con
                 for (int bl = blq; bl < t.nbt; bl += bstride) {
                     const double z = zl[bl * T + tt];
                     const double lam = bb_exp(z);
-                    lds[L.lam + NB * M.tcum[r] + bl * T + tt] = lam;
+                    if (KEEP_LAM) lds[L.lam + NB * M.tcum[r] + bl * T + tt] = lam;
                     aS += lam;
                     if (we) el += (double)M.counts[M.cnt_off[r] + (t.b0 + bl) * T + tt] * z - lam;
                     if (tt < T - 1) {

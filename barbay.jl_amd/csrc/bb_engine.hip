@@ -174,7 +174,8 @@ struct bb_handle {
     std::vector<bb_block_range> blocks;
     std::vector<void*> owned;          // device allocations
     int NB = 0, nthr = 0, nblk = 0, ngeno_blk = 0;
-    size_t lds_doubles = 0;
+    size_t lds_doubles = 0;            // dynamic LDS of the two-kernel path
+    size_t lds_doubles_p = 0;          // ... of the resident launch (adds the lambda table)
     long long b_lo = 0, b_hi = 0;      // barcode shard
     long long step = 0;                // host mirror of the device step counter
     int sample = 0;                    // next MC sample inside the current step (split-phase API)
@@ -346,8 +347,9 @@ static int setup_persistent(bb_handle* h) {
 #ifndef BB_EMU
     if (!why && want) {
         bb_persist_kernel k = persist_kernel(h->M.kind, P, h->nthr);
-        const int lds = (int)(h->lds_doubles * 8);
-        if (!k) why = "no kernel instance";
+        const int lds = (int)(h->lds_doubles_p * 8);
+        if (lds > 160 * 1024) why = "tile does not fit LDS with the lambda table";
+        else if (!k) why = "no kernel instance";
         else {
             if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
                 why = "cannot raise dynamic LDS";
@@ -379,14 +381,14 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     int rc = 0;
 #ifdef BB_EMU
     const int P = h->persist_P;
-    std::vector<double> lds((size_t)h->nblk * (h->lds_doubles + 64));
+    std::vector<double> lds((size_t)h->nblk * (h->lds_doubles_p + 64));
     auto run = [&](auto kindc, auto pc) {
         constexpr int KIND = decltype(kindc)::value;
         constexpr int PP = decltype(pc)::value;
         std::vector<BBPst<PP>> st((size_t)h->nblk * h->nthr);
-        auto cxof = [&](int b) { return BBCtx{h->nthr, b, lds.data() + (size_t)b * (h->lds_doubles + 64)}; };
+        auto cxof = [&](int b) { return BBCtx{h->nthr, b, lds.data() + (size_t)b * (h->lds_doubles_p + 64)}; };
         for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr); }
-        const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr);
+        const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
         memset(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4);
         int ok = 1;
         for (long long it = 0; it < nsteps; ++it) {
@@ -428,7 +430,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
         BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
         BB_HIP(hipMemsetAsync(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4, h->stream));
         A = make_args(h, h->step, 0, 1, true, false);
-        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB,
+        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB,
                            (unsigned long long)h->step, n);
         rc = launch_check();
         h->step += n;
@@ -652,7 +654,8 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         for (;;) {
             const int per_mutant = M.kind == 0 ? 2 : (M.kind == 1 ? 2 * M.E : (M.kind == 2 ? 3 : (M.kind == 3 ? 1 + 3 * M.R : M.E * (1 + 3 * M.R))));
             const long long pairs = (long long)NB * (M.Ttot + per_mutant) / 2;   // one pair of latents per thread is the sweet spot
-            nthr = pairs > 512 ? 1024 : (pairs > 256 ? 512 : 256);
+            // > 1 pair per thread: 512 threads (256-VGPR budget, up to 4 pairs) beat 1024 threads with spills (C3: 23.3k vs 17.0k steps/s)
+            nthr = pairs > 2048 ? 1024 : (pairs > 1024 ? 512 : (pairs > 512 ? 1024 : (pairs > 256 ? 512 : 256)));
             if ((ev = getenv("BB_TUNE_NTHR")) && atoi(ev) >= 64) nthr = atoi(ev) / 64 * 64;
             while (nthr < maxT) nthr <<= 1;
             const size_t need = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr).total * 8;
@@ -667,6 +670,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         h->NB = NB;
         h->nthr = nthr;
         h->lds_doubles = need / 8;
+        h->lds_doubles_p = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr, 1).total;
         h->nblk = (int)((nbar + NB - 1) / NB);
         h->ngeno_blk = M.G > 0 ? (int)std::min<long long>(((M.G + 1) / 2 + 255) / 256, 64) : 0;
 #ifndef BB_EMU

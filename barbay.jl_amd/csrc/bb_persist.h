@@ -73,7 +73,7 @@ BB_DEV void bb_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v)
 // ---- prologue: segment table, state into registers -------------------------------------------------
 template <int KIND, int P>
 BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     BBSeg* sg = (BBSeg*)(lds + L.seg);
@@ -107,7 +107,7 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
 template <int KIND, int P>
 BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                        unsigned long long step) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
@@ -146,7 +146,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     BB_PASS(cx, tid) { bb_effective_tables<KIND>(cx, tid, M, S, L, t, false); }
     BB_SYNC(cx);
     BB_STAMP(cx, S, 22);
-    bb_pass_moments<KIND>(cx, M, S, L, t, NB, false);
+    bb_pass_moments<KIND, true>(cx, M, S, L, t, NB, false);
     BB_STAMP(cx, S, 23);
     BB_STAMP(cx, S, 24);
 }
@@ -156,7 +156,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 template <int KIND, int P>
 BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                               unsigned long long step) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
     double* lds = cx.lds;
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
@@ -298,7 +298,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
 template <int KIND, int P>
 BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                        unsigned long long step) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
@@ -361,7 +361,7 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 template <int KIND, int P>
 BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                          unsigned long long step_end) {
-    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
     double* lds = cx.lds;
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
@@ -390,14 +390,14 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
     extern __shared__ __attribute__((aligned(16))) double bbp_smem[];
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bbp_smem};
     BBPst<P> st;
-    int* ok_slot = (int*)(bbp_smem + bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr).misc) + 1;
+    int* ok_slot = (int*)(bbp_smem + bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1).misc) + 1;
     bbp_prologue<KIND, P>(cx, M, S, A, NB, &st);
     int done = 0;
     for (; done < nsteps; ++done) {
         const unsigned long long step = step0 + (unsigned long long)done;
         bbp_sample<KIND, P>(cx, M, S, A, NB, &st, step);
         {
-            const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr);
+            const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
             const unsigned epoch = (unsigned)(done + 1);
             const int par = (int)(step & 1);
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
