@@ -31,8 +31,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def cpu_baseline(wl, seconds_budget: float = 20.0):
     """Time the oracle's fused C port (oracle/c/bb_port.c) on the same workload, same options."""
     from oracle import port
-    ncores = os.cpu_count() or 1
-    return port.time_workload(wl, ncores, seconds_budget)
+    return port.time_workload(wl, port.usable_cores(), seconds_budget)
 
 
 def main():

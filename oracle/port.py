@@ -119,6 +119,25 @@ def spec_from_workload(wl) -> ModelSpec:
                      n_neutral=wl.n_neutral, n_bc=wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def time_workload(wl, ncores: int, seconds_budget: float = 20.0) -> dict:
     """steps/s of the port on `wl`: running-window TruncatedADAGrad(0.1, 40, 100), S = 1, same Philox
     stream as the engine; one thread and all `ncores` threads, each on a bounded number of steps."""
@@ -127,6 +146,7 @@ def time_workload(wl, ncores: int, seconds_budget: float = 20.0) -> dict:
     p = Port(sp)
     mu0, om0 = advi.meanfield_init(42, sp.D)
     out = {}
+    ncores = max(1, min(ncores, usable_cores()))
     for label, nt in (("1", 1), ("all", ncores)):
         p.run(mu0, om0, 2, seed=42, nthreads=nt)          # touch pages, spin up the team
         n, t0 = 0, time.perf_counter()
