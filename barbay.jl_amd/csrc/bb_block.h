@@ -27,7 +27,6 @@ struct BBCtx { int nthr; int block; double* lds; };
 #define BB_PASS(cx, tid) for (int tid = 0; tid < (cx).nthr; ++tid)
 #define BB_SYNC(cx) ((void)0)
 BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
-BB_DEV void bb_sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 #else
 #include <hip/hip_runtime.h>
 #define BB_DEV __device__ __forceinline__
@@ -35,7 +34,6 @@ struct BBCtx { int nthr; int block; double* lds; };
 #define BB_PASS(cx, tid) for (int tid = threadIdx.x, _once = 1; _once; _once = 0)
 #define BB_SYNC(cx) __syncthreads()
 BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
-BB_DEV void bb_sincospi(double x, double* s, double* c) { sincospi(x, s, c); }
 #endif
 
 // In-kernel stamps (diagnostic build only, -DBB_STAMPS): s_memtime at pass boundaries of every block,

@@ -994,11 +994,6 @@ static int build_graph(bb_handle* h, int steps) {
 }
 #endif
 
-static int check_finite(bb_handle* h) {
-    if (h->o.elbo_every <= 0) return 0;
-    return 0;
-}
-
 extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
     if (h->sample != 0) return bb_fail(BB_ERR_INVALID, "a split-phase step is in flight");
@@ -1045,7 +1040,7 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     h->last_run_ms = ms;
 #endif
     if (h->persist_P > 0 && (rc = check_persistent(h))) return rc;
-    return check_finite(h);
+    return BB_OK;
 }
 
 extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {

@@ -31,7 +31,6 @@ extern "C" {
 #define BB_ERR_DEVICE (-2)    /* HIP runtime error                           */
 #define BB_ERR_COMM (-3)      /* RCCL error / communicator not initialised   */
 #define BB_ERR_UNSUPPORTED (-4)
-#define BB_ERR_NUMERIC (-5)   /* non-finite ELBO partials detected           */
 
 /* model kinds: BarBay.model.* entries on the hot path */
 #define BB_MODEL_FITNESS 0    /* fitness_normal            src/model_fitness_normal.jl:120-272 */
