@@ -143,7 +143,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.zs3 = o;  o += NB * (kind == 4 ? E : 1);
     L.seff = o; o += NB * X;
     L.weff = o; o += NB * X;
-    L.res = o;  o += NB * (Ttot - R);
+    L.res = o;  o += 0;   // (residuals are formed inline: bb_residual)
     L.As = o;   o += NB * X;
     L.Qs = o;   o += NB * X;
     L.acc = o;  o += (BB_NQ + 1) * nthr;
@@ -797,29 +797,24 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
     bb_finalize_finish<KIND>(cx, M, S, A, L);
 }
 
-// passes R + U: residuals r = (l[t+1] - l[t]) - s_eff - c_t of every (barcode, time step), then the per-unit
-// sums As = sum_t w r (= dlogp/ds_eff) and Qs = sum_t (w r^2 - 1) (= dlogp/dlogsigma_eff).
+// Residual r = (l[t+1] - l[t]) - s_eff - c_t of (barcode bl, time step tt) of replicate r, formed from the staged
+// samples where it is needed (no residual table, no separate pass).
+template <int KIND>
+BB_DEV double bb_residual(const double* lds, const DevModel& M, const BBLds& L, const BBTile& t, int NB, int X, int r, int bl, int tt) {
+    const int T = M.T[r], tc = M.tcum[r];
+    const double* zl = lds + L.zl + NB * tc + bl * T + tt;
+    double a = zl[1] - zl[0];
+    if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof<KIND>(M, r, tt)];
+    else if (KIND == 3 && M.quirk)   // ragged method: residual against -s_pop[jq] instead of -s_pop[tt]
+        a += lds[L.zgl + M.off_t[r] + bb_qj(M, T - 1, tt, t.b0 + bl)] - lds[L.zgl + M.off_t[r] + tt];
+    return a - lds[L.cc + tc + tt];
+}
+
+// pass U: the per-unit sums As = sum_t w r (= dlogp/ds_eff) and Qs = sum_t (w r^2 - 1) (= dlogp/dlogsigma_eff).
 template <int KIND>
 BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, const BBTile& t, int NB) {
     double* lds = cx.lds;
     const int X = bb_xdim<KIND>(M);
-    for (int r = 0; r < M.R; ++r) {
-        const int T = M.T[r], T1 = T - 1, tc = M.tcum[r];
-        const double* zl = lds + L.zl + NB * tc;
-        double* res = lds + L.res + NB * (tc - r);
-        const unsigned magic1 = M.Tmagic1[r];
-        BB_PASS(cx, tid) {
-            for (int j = tid; j < t.nbt * T1; j += cx.nthr) {
-                const int bl = T1 == 1 ? j : (int)bb_umulhi((unsigned)j, magic1), tt = j - bl * T1;
-                double a = zl[bl * T + tt + 1] - zl[bl * T + tt];
-                if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof<KIND>(M, r, tt)];
-                else if (KIND == 3 && M.quirk)   // residual against -s_pop[jq] instead of -s_pop[tt]
-                    a += lds[L.zgl + M.off_t[r] + bb_qj(M, T1, tt, t.b0 + bl)] - lds[L.zgl + M.off_t[r] + tt];
-                res[j] = a - lds[L.cc + tc + tt];
-            }
-        }
-    }
-    BB_SYNC(cx);
     BB_STAMP(cx, S, 13);
 
     // pass U: per-unit sums  As = sum_t w r  (= dlogp/ds_eff),  Qs = sum_t (w r^2 - 1)  (= dlogp/dlogsigma_eff)
@@ -831,11 +826,10 @@ BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState
                 const double w = lds[L.weff + u];
                 const int r = KIND == 3 ? x : (KIND == 4 ? x / M.E : 0);
                 const int T1 = M.T[r] - 1;
-                const double* res = lds + L.res + NB * (M.tcum[r] - r) + bl * T1;
                 for (int tt = 0; tt < T1; ++tt) {
                     if (KIND == 1 && M.env_idx[tt + 1] != x) continue;
                     if (KIND == 4 && M.env_idx[M.tcum[r] + tt + 1] != x - r * M.E) continue;
-                    const double rr = res[tt];
+                    const double rr = bb_residual<KIND>(lds, M, L, t, NB, X, r, bl, tt);
                     as += w * rr;
                     qs += w * rr * rr - 1.0;
                 }
@@ -859,7 +853,6 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
     switch (s.kind) {
     case SK_L: {
         const int r = s.r, T = M.T[r], T1 = T - 1, tc = M.tcum[r];
-        const double* res = lds + L.res + NB * (tc - r);
         const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
         const bool mut = bl >= ns;
         const double lam = LAM_IN_LDS ? lds[L.lam + NB * tc + j] : bb_exp(z);   // the resident launch keeps the moments pass's table
@@ -870,12 +863,12 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
         if (tt < T1) {
             const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)]
                                  : lds[L.wbar + tc + (qk ? bb_qj(M, T1, tt, t.b0 + bl) : tt)];
-            g += w * res[bl * T1 + tt];
+            g += w * bb_residual<KIND>(lds, M, L, t, NB, X, r, bl, tt);
         }
         if (tt > 0) {
             const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)]
                                  : lds[L.wbar + tc + (qk ? bb_qj(M, T1, tt - 1, t.b0 + bl) : tt - 1)];
-            g -= w * res[bl * T1 + tt - 1];
+            g -= w * bb_residual<KIND>(lds, M, L, t, NB, X, r, bl, tt - 1);
         }
         return g;
     }
