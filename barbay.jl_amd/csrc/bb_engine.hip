@@ -94,17 +94,22 @@ static int dsync(bbStream s) { BB_HIP(hipStreamSynchronize(s)); return 0; }
 
 extern __shared__ __attribute__((aligned(16))) double bb_smem[];
 
+// (descriptors by pointer: scalar loads on demand; by value they cost dozens of SGPR spills per kernel)
 template <int KIND>
-__global__ void __launch_bounds__(1024) k_sample(DevModel M, DevState S, RunArgs A, int NB) {
+__global__ void __launch_bounds__(1024) k_sample(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, RunArgs A, int NB) {
+    const DevModel& M = *Mp;
+    const DevState& S = *Sp;
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_sample<KIND>(cx, M, S, A, NB);
 }
 template <int KIND>
-__global__ void __launch_bounds__(1024) k_update(DevModel M, DevState S, RunArgs A, int NB) {
+__global__ void __launch_bounds__(1024) k_update(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, RunArgs A, int NB) {
+    const DevModel& M = *Mp;
+    const DevState& S = *Sp;
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_update<KIND>(cx, M, S, A, NB);
 }
-typedef void (*bb_step_kernel)(DevModel, DevState, RunArgs, int);
+typedef void (*bb_step_kernel)(const DevModel*, const DevState*, RunArgs, int);
 static bb_step_kernel sample_kernel(int kind) {
     switch (kind) { case 0: return k_sample<0>; case 1: return k_sample<1>; case 2: return k_sample<2>; case 3: return k_sample<3>; default: return k_sample<4>; }
 }
@@ -329,6 +334,14 @@ static long long tile_pairs_bound(const bb_handle* h) {
     return p;
 }
 
+// device copies of the descriptors (kernels read them through pointers); re-sent whenever the host copy changes
+static int sync_descriptors(bb_handle* h) {
+    int rc;
+    if (!h->dM && ((rc = dalloc(h, &h->dM, 1)) || (rc = dalloc(h, &h->dS, 1)))) return rc;
+    if ((rc = h2d(h->dM, &h->M, sizeof(DevModel), h->stream)) || (rc = h2d(h->dS, &h->S, sizeof(DevState), h->stream))) return rc;
+    return 0;
+}
+
 static int setup_persistent(bb_handle* h) {
     h->persist_P = 0;
     const char* ev = getenv("BB_NO_PERSIST");
@@ -367,12 +380,7 @@ static int setup_persistent(bb_handle* h) {
         if (h->o.launch_mode == 2) return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2 (persistent) not possible: %s", why);
         return 0;
     }
-    if (want) {
-        h->persist_P = P;
-        int rc;
-        if ((rc = dalloc(h, &h->dM, 1)) || (rc = dalloc(h, &h->dS, 1))) return rc;
-        if ((rc = h2d(h->dM, &h->M, sizeof(DevModel), h->stream)) || (rc = h2d(h->dS, &h->S, sizeof(DevState), h->stream))) return rc;
-    }
+    if (want) h->persist_P = P;
     return 0;
 }
 
@@ -725,6 +733,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         h->bytes_update = (int64_t)((16.0 + 16.0 + optb) * Dsh + cnts);
     }
     BB_TRY(setup_persistent(h));
+    BB_TRY(sync_descriptors(h));
     BB_TRY(bb_init_meanfield(h));
     *out = h;
     return BB_OK;
@@ -812,7 +821,7 @@ static int launch_sample(bb_handle* h, const RunArgs& A) {
         }
     });
 #else
-    hipLaunchKernelGGL(sample_kernel(h->M.kind), dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
+    hipLaunchKernelGGL(sample_kernel(h->M.kind), dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB);
 #endif
     return LAUNCH_CHECK();
 }
@@ -828,7 +837,7 @@ static int launch_update(bb_handle* h, const RunArgs& A) {
         }
     });
 #else
-    hipLaunchKernelGGL(update_kernel(h->M.kind), dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, h->M, h->S, A, h->NB);
+    hipLaunchKernelGGL(update_kernel(h->M.kind), dim3(h->nblk), dim3(h->nthr), h->lds_doubles * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB);
 #endif
     return LAUNCH_CHECK();
 }
@@ -1111,6 +1120,7 @@ extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega,
     }
     double* saved_es = h->S.elbo_sample;
     if (es) h->S.elbo_sample = es;
+    if ((rc = sync_descriptors(h))) return rc;
     for (int s = 0; s < S && !rc; ++s) {
         RunArgs A = make_args(h, h->step, s, S, false, true);
         rc = sample_half(h, A);
@@ -1122,6 +1132,7 @@ extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega,
     h->S.elbo_sample = saved_es;
     if (es) dfree(es);
     h->S.eps_in = nullptr;
+    { int rcs = sync_descriptors(h); if (!rc) rc = rcs; }
     if (!rc && grad_mu) rc = d2h(grad_mu, h->S.gacc_mu, D * 8, h->stream);
     if (!rc && grad_omega) rc = d2h(grad_omega, h->S.gacc_om, D * 8, h->stream);
     int rc2 = d2d(h->S.mu, h->bak_mu, D * 8, h->stream);
