@@ -1014,27 +1014,60 @@ BB_DEV void bb_block_geno(BBCtx& cx, const DevModel& M, const DevState& S, const
     }
 }
 
-// gsum[g] = sum over the genotype's mutants (CSR order) of ds: deterministic segmented sum.
+// gsum[g] = sum over the genotype's mutants (CSR order) of ds: deterministic segmented sum.  Eight lanes share a
+// genotype (lane c adds members k = c, c + 8, ...), the eight partial sums are added in lane order.
 BB_DEV void bb_block_geno_sum(BBCtx& cx, const DevModel& M, const DevState& S, int nblocks, long long m_lo, long long m_hi) {
-    BB_PASS(cx, tid) {
-        for (long long g = (long long)cx.block * cx.nthr + tid; g < M.G; g += (long long)nblocks * cx.nthr) {
+    double* lds = cx.lds;                       // nthr doubles
+    const int per_block = cx.nthr / 8;
+    for (long long g0 = (long long)cx.block * per_block; g0 < M.G; g0 += (long long)nblocks * per_block) {
+        BB_PASS(cx, tid) {
+            const long long g = g0 + (tid >> 3);
+            const int c = tid & 7;
             double s = 0.0;
-            for (int k = M.geno_ptr[g]; k < M.geno_ptr[g + 1]; ++k) {
-                const int m = M.geno_mem[k];
-                if (m >= m_lo && m < m_hi) s += S.ds[m];
+            if (g < M.G) {
+                for (int k = M.geno_ptr[g] + c; k < M.geno_ptr[g + 1]; k += 8) {
+                    const int m = M.geno_mem[k];
+                    if (m >= m_lo && m < m_hi) s += S.ds[m];
+                }
             }
-            S.gsum[g] = s;
+            lds[tid] = s;
+        }
+        BB_SYNC(cx);
+        BB_PASS(cx, tid) {
+            const long long g = g0 + tid;
+            if (tid < per_block && g < M.G) {
+                double s = 0.0;
+                for (int c = 0; c < 8; ++c) s += lds[tid * 8 + c];
+                S.gsum[g] = s;
+            }
+        }
+        BB_SYNC(cx);
+    }
+}
+
+// partials [K][nblk] -> totals [K] (one block), two-level fixed order: 16 strided partial sums per row, then one
+// add chain; row K-1 additionally takes the theta-block ELBO partials.
+BB_DEV void bb_block_reduce(BBCtx& cx, const DevModel& M, const DevState& S, int nblk, int ngeno_blocks) {
+    double* lds = cx.lds;                       // 16 K doubles
+    BB_PASS(cx, tid) {
+        for (int w = tid; w < M.K * 16; w += cx.nthr) {
+            const int k = w >> 4, c = w & 15;
+            const double* row = S.partials + (long long)k * nblk;
+            double s = 0.0;
+            for (int j0 = c; j0 < nblk; j0 += 128) {
+                double v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (j0 + 16 * i < nblk) ? row[j0 + 16 * i] : 0.0;
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            lds[w] = s;
         }
     }
     BB_SYNC(cx);
-}
-
-// partials [K][nblk] -> totals [K] (one block); row K-1 additionally takes the theta-block ELBO partials.
-BB_DEV void bb_block_reduce(BBCtx& cx, const DevModel& M, const DevState& S, int nblk, int ngeno_blocks) {
     BB_PASS(cx, tid) {
         for (int k = tid; k < M.K; k += cx.nthr) {
             double s = 0.0;
-            for (int j = 0; j < nblk; ++j) s += S.partials[(long long)k * nblk + j];
+            for (int c = 0; c < 16; ++c) s += lds[k * 16 + c];
             if (k == M.K - 1) for (int j = 0; j < ngeno_blocks; ++j) s += S.geno_el[j];
             S.totals[k] = s;
         }

@@ -843,9 +843,9 @@ static int launch_update(bb_handle* h, const RunArgs& A) {
 }
 static int launch_reduce(bb_handle* h) {
 #ifdef BB_EMU
-    emu_launch(1, 256, 0, [&](BBCtx& cx) { bb_block_reduce(cx, h->M, h->S, h->nblk, h->ngeno_blk); });
+    emu_launch(1, 256, (size_t)16 * h->M.K, [&](BBCtx& cx) { bb_block_reduce(cx, h->M, h->S, h->nblk, h->ngeno_blk); });
 #else
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, h->stream, h->M, h->S, h->nblk, h->ngeno_blk);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), (size_t)16 * h->M.K * 8, h->stream, h->M, h->S, h->nblk, h->ngeno_blk);
 #endif
     return LAUNCH_CHECK();
 }
@@ -860,9 +860,11 @@ static int launch_geno(bb_handle* h, const RunArgs& A, int do_update, int do_sam
 static int launch_geno_sum(bb_handle* h) {
     const long long m_lo = std::max(h->b_lo, h->M.nn) - h->M.nn, m_hi = std::max(h->b_hi, h->M.nn) - h->M.nn;
 #ifdef BB_EMU
-    emu_launch(h->ngeno_blk, 256, 0, [&](BBCtx& cx) { bb_block_geno_sum(cx, h->M, h->S, h->ngeno_blk, m_lo, m_hi); });
+    const int gsb = (int)std::min<long long>((h->M.G + 31) / 32, 1024);      // 32 genotypes per 256-thread block
+    emu_launch(gsb, 256, 256, [&](BBCtx& cx) { bb_block_geno_sum(cx, h->M, h->S, gsb, m_lo, m_hi); });
 #else
-    hipLaunchKernelGGL(k_geno_sum, dim3(h->ngeno_blk), dim3(256), 0, h->stream, h->M, h->S, m_lo, m_hi);
+    const int gsb = (int)std::min<long long>((h->M.G + 31) / 32, 1024);
+    hipLaunchKernelGGL(k_geno_sum, dim3(gsb), dim3(256), 256 * 8, h->stream, h->M, h->S, m_lo, m_hi);
 #endif
     return LAUNCH_CHECK();
 }
