@@ -1023,8 +1023,11 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
     // pattern must repeat with the graph -> only when ELBO recording is off; no collectives inside.
     int gs = h->o.steps_per_graph == 0 ? 50 : h->o.steps_per_graph;
-    // (the RCCL all-reduce of a sharded run is captured too; if that capture fails once, launches stay eager)
-    const bool graph_ok = gs > 0 && h->o.elbo_every == 0 && !h->graph_failed && !getenv("BB_NO_GRAPH");
+    // A sharded step (with its RCCL all-reduce) can be captured too (BB_GRAPH_COLLECTIVE=1; equal results, no gain
+    // measured: the step is GPU-bound), but multi-rank capture could not be exercised on the one-GPU boxes this was
+    // developed on, so sharded runs launch eagerly by default.
+    const bool graph_ok = gs > 0 && h->o.elbo_every == 0 && !h->graph_failed && !getenv("BB_NO_GRAPH") &&
+                          ((h->o.world_size == 1 && !h->force_reduce) || getenv("BB_GRAPH_COLLECTIVE"));
     if (graph_ok) {
         gs &= ~1;
         if (gs < 2) gs = 2;
