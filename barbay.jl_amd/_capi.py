@@ -23,7 +23,7 @@ EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
     "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_run", "bb_run_profiled",
     "bb_get_posterior", "bb_elbo_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats",
-    "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply",
+    "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply", "bb_hier_units", "bb_hier_fitness",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -100,6 +100,9 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.bb_comm_init.argtypes = [vp, C.c_void_p]
     lib.bb_step_moments.argtypes = [vp, _dp]
     lib.bb_step_apply.argtypes = [vp, _dp]
+    lib.bb_hier_units.argtypes = [vp]
+    lib.bb_hier_units.restype = C.c_int64
+    lib.bb_hier_fitness.argtypes = [vp, C.c_int32, C.c_uint64, _dp, _dp]
     return lib
 
 
@@ -290,6 +293,17 @@ class Engine:
         s = bb_stats()
         self._check(self._lib.bb_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in bb_stats._fields_}
+
+    def hier_units(self) -> int:
+        """Length of the theta_tilde block (0 for the non-hierarchical models)."""
+        return int(self._lib.bb_hier_units(self._h))
+
+    def hier_fitness(self, n_samples: int = 10_000, seed: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """Device-side `process_hierarchical_samples!`: (median, std) of theta + exp(logtau) * theta_tilde per unit."""
+        n = int(self._lib.bb_hier_units(self._h))
+        med, sd = np.empty(n), np.empty(n)
+        self._check(self._lib.bb_hier_fitness(self._h, n_samples, seed, _ptr(med), _ptr(sd)))
+        return med, sd
 
     def make_comm_id(self) -> bytes:
         buf = C.create_string_buffer(BB_COMM_ID_BYTES)

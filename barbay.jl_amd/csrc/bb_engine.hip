@@ -10,6 +10,7 @@
 #include "../../include/barbay_hip.h"
 #include "bb_block.h"
 #include "bb_persist.h"
+#include "bb_hier.h"
 
 #include <algorithm>
 #include <cmath>
@@ -131,6 +132,10 @@ __global__ void __launch_bounds__(256) k_reduce(DevModel M, DevState S, int nblk
 __global__ void __launch_bounds__(256) k_init(DevModel M, DevState S, unsigned long long seed) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_init(cx, M, S, seed, (int)gridDim.x);
+}
+__global__ void __launch_bounds__(1024) k_hier(HierArgs H) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_hier(cx, H, (int)gridDim.x);
 }
 __global__ void __launch_bounds__(256) k_normals(unsigned long long seed, unsigned step, unsigned stream, long long lo,
                                                  long long hi, double* out) {
@@ -1201,6 +1206,55 @@ extern "C" int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n) {
     int rc = dsync(h->stream);
     if (rc) return rc;
     return d2h(out, h->S.stamps, (size_t)std::min(n, have) * 8, h->stream);
+}
+
+extern "C" int64_t bb_hier_units(const bb_handle* h) {
+    if (!h || h->M.kind < BB_MODEL_GENOTYPE) return 0;
+    return h->M.blk_hi[BK_TT] - h->M.blk_lo[BK_TT];
+}
+
+extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* stdv) {
+    if (!h || !median || !stdv) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (h->M.kind < BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_INVALID, "bb_hier_fitness applies to the hierarchical models only");
+    if (n_samples < 2 || n_samples > 16384) return bb_fail(BB_ERR_UNSUPPORTED, "n_samples must be in 2..16384");
+    if (h->o.world_size > 1) return bb_fail(BB_ERR_UNSUPPORTED, "bb_hier_fitness needs the whole posterior on one handle");
+    const long long n = bb_hier_units(h);
+    const size_t D = (size_t)h->M.D;
+    int rc;
+    // posterior sigma = softplus(omega) into the (free between steps) z scratch array
+    std::vector<double> om(D);
+    if ((rc = dsync(h->stream)) || (rc = d2h(om.data(), h->S.om, D * 8, h->stream))) return rc;
+    for (size_t i = 0; i < D; ++i) om[i] = std::max(om[i], 0.0) + log1p(exp(-fabs(om[i])));
+    if ((rc = h2d(h->S.zsv, om.data(), D * 8, h->stream))) return rc;
+    HierArgs H;
+    memset(&H, 0, sizeof H);
+    H.mean = h->S.mu;
+    H.sigma = h->S.zsv;
+    H.median_out = h->S.asv;           // n <= D: scratch arrays are free between steps
+    H.std_out = h->S.hsv;
+    H.n_units = n;
+    H.lo_theta = h->M.blk_lo[BK_S];
+    H.lo_tt = h->M.blk_lo[BK_TT];
+    H.lo_lt = h->M.blk_lo[BK_LT];
+    H.theta_mod = h->M.kind == BB_MODEL_GENOTYPE ? 0 : (h->M.blk_hi[BK_S] - h->M.blk_lo[BK_S]);
+    H.geno_idx = h->M.geno_idx;
+    H.n_samples = n_samples;
+    H.n_pad = 2;
+    while (H.n_pad < n_samples) H.n_pad <<= 1;
+    H.seed = seed;
+    const int nthr = H.n_pad >= 2048 ? 1024 : 256;
+    const size_t lds = (size_t)H.n_pad + nthr + 8;
+    const int nb = (int)std::min<long long>(n, 2048);
+#ifdef BB_EMU
+    emu_launch(nb, nthr, lds, [&](BBCtx& cx) { bb_block_hier(cx, H, nb); });
+#else
+    if (lds * 8 > 64 * 1024 && hipFuncSetAttribute((const void*)k_hier, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds * 8)) != hipSuccess)
+        return bb_fail(BB_ERR_DEVICE, "cannot raise dynamic LDS to %zu bytes", lds * 8);
+    hipLaunchKernelGGL(k_hier, dim3(nb), dim3(nthr), lds * 8, h->stream, H);
+    if ((rc = launch_check())) return rc;
+#endif
+    if ((rc = d2h(median, H.median_out, (size_t)n * 8, h->stream))) return rc;
+    return d2h(stdv, H.std_out, (size_t)n * 8, h->stream);
 }
 
 extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {

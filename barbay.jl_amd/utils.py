@@ -208,16 +208,19 @@ def advi_to_df(data: pd.DataFrame, dist, vars: Sequence[str], *, id_col="barcode
             ids[lo:hi] = sum([[b] * n_env for _ in range(n_rep) for b in output.bc_ids], [])
     df["id"] = ids
     if len(var_groups) == 7 and (n_rep > 1 or genotype_col is not None):          # :1457-1459
-        df = _process_hierarchical_samples(df, output, n_samples, rep_col, env_col, genotype_col, rng)
+        df = _process_hierarchical_samples(df, output, n_samples, rep_col, env_col, genotype_col, rng,
+                                           device=getattr(dist, "hier", None))
     return df
 
 
-def _process_hierarchical_samples(df, output, n_samples, rep_col, env_col, genotype_col, rng):
+def _process_hierarchical_samples(df, output, n_samples, rep_col, env_col, genotype_col, rng, device=None):
     """process_hierarchical_samples! (src/utils.jl:1284-1343): draws n_samples Normal samples per
     parameter and appends derived `bc_fitness` rows reported as MEDIAN (under the column `mean`) and std.
     For the genotype model theta is indexed per genotype; the reference's `hcat(repeat([θ_mat], n_rep)...)`
     only lines up when every mutant has its own hyper-fitness (the replicate model), so the genotype case
-    gathers theta by the mutant's genotype instead (documented deviation)."""
+    gathers theta by the mutant's genotype instead (documented deviation).
+    `device` = (n_samples, median, std) computed by the engine (`bb_hier_fitness`, csrc/bb_hier.h) is used when it
+    was drawn with the requested n_samples; the numpy draws below serve a `dist` that did not come from the engine."""
     rng = rng or np.random.default_rng()
     th = df[df.vartype == "bc_hyperfitness"]
     ta = df[df.vartype == "bc_deviations"]
@@ -234,7 +237,10 @@ def _process_hierarchical_samples(df, output, n_samples, rep_col, env_col, genot
     th_m, th_s = th["mean"].to_numpy(), th["std"].to_numpy()
     ta_m, ta_s = ta["mean"].to_numpy(), ta["std"].to_numpy()
     tt_m, tt_s = tt["mean"].to_numpy(), tt["std"].to_numpy()
-    for lo in range(0, n_unit, chunk):
+    use_dev = device is not None and device[0] == n_samples and len(device[1]) == n_unit
+    if use_dev:
+        med, sd = np.asarray(device[1]), np.asarray(device[2])
+    for lo in range(0, 0 if use_dev else n_unit, chunk):
         hi = min(lo + chunk, n_unit)
         c = col_of[lo:hi]
         theta = rng.normal(th_m[c], th_s[c], (n_samples, hi - lo))

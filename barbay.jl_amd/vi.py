@@ -61,15 +61,20 @@ def make_engine(bayes_model: BayesModel, advi: ADVI, opt, seed: int = 0, device:
                   ragged_method=bayes_model.ragged and bayes_model.kind == "replicate", **okw, **engine_kwargs)
 
 
-def vi(bayes_model: BayesModel, advi: ADVI, optimizer=None, seed: int = 0, device: int = 0, **engine_kwargs):
+def vi(bayes_model: BayesModel, advi: ADVI, optimizer=None, seed: int = 0, device: int = 0, hier_samples: int = 10_000,
+       **engine_kwargs):
     """`Turing.vi(model, advi; optimizer)`: returns q with q.dist.m, q.dist.σ, q.transform.ranges_out --
-    the fields `utils.advi_to_df` reads (src/utils.jl:1049, 1060)."""
+    the fields `utils.advi_to_df` reads (src/utils.jl:1049, 1060).  For the hierarchical models q.hier holds the
+    device-side `process_hierarchical_samples!` result (n_samples, median, std) that `advi_to_df` appends."""
     with make_engine(bayes_model, advi, optimizer or TruncatedADAGrad(), seed, device, **engine_kwargs) as e:
         e.run(advi.max_iters)
         m, s = e.posterior()
         ranges = [(lo, hi) for _, lo, hi in e.layout()]
+        hier = None
+        if hier_samples and e.hier_units() > 0 and engine_kwargs.get("world_size", 1) == 1:
+            hier = (hier_samples,) + tuple(e.hier_fitness(hier_samples, seed=seed))
     dist = SimpleNamespace(m=m, σ=s, sigma=s)
-    return SimpleNamespace(dist=dist, transform=SimpleNamespace(ranges_out=ranges))
+    return SimpleNamespace(dist=dist, transform=SimpleNamespace(ranges_out=ranges), hier=hier)
 
 
 def advi(*, data, outputname: Optional[str] = None, model: Callable, model_kwargs: Optional[Dict] = None,

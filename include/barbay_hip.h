@@ -178,6 +178,13 @@ int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const doub
  * first_step, first_step + elbo_every, ... ; NaN where not recorded/kept. */
 int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out);
 
+/* `process_hierarchical_samples!` of utils.advi_to_df (src/utils.jl:1284-1343) on the device, for the hierarchical
+ * models (genotype, replicate, multienv_replicate): for every unit of the theta_tilde block, n_samples draws of
+ * theta + exp(logtau) * theta_tilde from the current mean-field posterior; median (reported by the reference under
+ * the column name `mean`) and corrected std.  n_samples <= 16384.  median / std: [bb_hier_units(h)]. */
+int64_t bb_hier_units(const bb_handle* h);
+int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* std);
+
 /* The engine's normal stream for (step, stream) over latents [lo, hi), for checks. */
 int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, int64_t hi, double* out);
 

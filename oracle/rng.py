@@ -70,3 +70,34 @@ def normals(seed: int, step: int, stream: int, D: int, lo: int = 0, hi: int | No
     out[1::2] = r * np.sin(2.0 * np.pi * u2)
     start = lo - 2 * (lo // 2)
     return out[start:start + (hi - lo)]
+
+
+def pairs(seed: int, q, step, stream: int):
+    """(n0, n1) of arbitrary Philox counters (q, step, stream) -- vectorised over q / step."""
+    q = np.asarray(q, dtype=np.uint64)
+    step = np.broadcast_to(np.asarray(step, dtype=np.uint64), q.shape)
+    o0, o1, o2, o3 = philox4x32_10(q & _MASK, q >> np.uint64(32), step & _MASK, stream & 0xFFFFFFFF,
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u1 = (((o1 << np.uint64(32) | o0) >> np.uint64(11)).astype(np.float64) + 1.0) * 2.0 ** -53
+    u2 = ((o3 << np.uint64(32) | o2) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    r = np.sqrt(-2.0 * np.log(u1))
+    return r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)
+
+
+STREAM_HIER_THETA = 0xFFFFFFF0
+STREAM_HIER_UNIT = 0xFFFFFFF1
+
+
+def hier_fitness(seed: int, n_samples: int, theta_idx, m_th, s_th, m_lt, s_lt, m_tt, s_tt):
+    """Oracle of bb_hier_fitness (barbay.jl_amd/csrc/bb_hier.h): per unit u, draws of
+    theta[theta_idx[u]] + exp(logtau_u) * theta_tilde_u from the engine's hier streams; (median, corrected std)."""
+    j = np.arange(n_samples, dtype=np.uint64)
+    med, sd = np.empty(len(theta_idx)), np.empty(len(theta_idx))
+    for u, ith in enumerate(theta_idx):
+        a, b = pairs(seed, (np.uint64(ith) << np.uint64(20)) | (j >> np.uint64(1)), j & np.uint64(1), STREAM_HIER_THETA)
+        n_th = np.where(j & np.uint64(1), b, a)
+        n_lt, n_tt = pairs(seed, np.full(n_samples, u, dtype=np.uint64), j, STREAM_HIER_UNIT)
+        s = (m_th[ith] + s_th[ith] * n_th) + np.exp(m_lt[u] + s_lt[u] * n_lt) * (m_tt[u] + s_tt[u] * n_tt)
+        med[u] = np.median(s)
+        sd[u] = s.std(ddof=1)
+    return med, sd

@@ -87,3 +87,8 @@ def test_ragged_method_neutrals_across_tiles(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NTHR", "128")
     c.case_ragged_method(emu_lib, 1)
     c.case_ragged_method(emu_lib, 2)
+
+
+@pytest.mark.parametrize("name", ["genotype", "replicate_ragged", "multienv_replicate_3d"])
+def test_hier_fitness(emu_lib, name):
+    c.case_hier_fitness(emu_lib, name)

@@ -173,3 +173,8 @@ def test_full_size_other_configs(hip_lib, cfg):
 @pytest.mark.parametrize("mode", [1, 2])
 def test_ragged_method_pairing(hip_lib, mode):
     c.case_ragged_method(hip_lib, mode)
+
+
+@pytest.mark.parametrize("name", ["genotype", "replicate_ragged", "multienv_replicate_3d"])
+def test_hier_fitness(hip_lib, name):
+    c.case_hier_fitness(hip_lib, name)

@@ -28,6 +28,16 @@ def test_hierarchical_replicates_and_uneven():                                  
     r = bb.vi.advi(data=data, model=bb.model.replicate_fitness_normal, rep_col="rep", advi=bb.vi.ADVI(1, 1), verbose=False)
     assert {"rep", "id", "vartype"} <= set(r.columns)
     assert {"bc_hyperfitness", "bc_noncenter", "bc_deviations"} <= set(r.vartype)
+    # derived bc_fitness rows (process_hierarchical_samples!, src/utils.jl:1284-1343) come from the device sampler:
+    # draw-for-draw equal to the oracle's restatement on the posterior the frame itself reports
+    from oracle import rng
+    th, tt, lt = (r[r.vartype == v] for v in ("bc_hyperfitness", "bc_noncenter", "bc_deviations"))
+    fit = r[r.vartype == "bc_fitness"]
+    assert len(fit) == len(tt) and list(fit["id"]) == list(lt["id"])
+    idx = np.arange(len(tt)) % len(th)
+    med, sd = rng.hier_fitness(0, 10_000, idx[:25], th["mean"].to_numpy(), th["std"].to_numpy(), lt["mean"].to_numpy(),
+                               lt["std"].to_numpy(), tt["mean"].to_numpy(), tt["std"].to_numpy())
+    assert np.abs(fit["mean"].to_numpy()[:25] - med).max() < 1e-10 and np.abs(fit["std"].to_numpy()[:25] - sd).max() < 1e-10
     uneven = data[(data.rep != data.rep.max()) | (data.time != data.time.max())]
     r2 = bb.vi.advi(data=uneven, model=bb.model.replicate_fitness_normal, rep_col="rep", advi=bb.vi.ADVI(1, 1), verbose=False)
     assert isinstance(r2, pd.DataFrame)
