@@ -847,7 +847,7 @@ BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState
 // Likelihood part of d logjoint / d z for latent j of segment s (z = its sample), gathered from the LDS tables.
 template <int KIND, bool LAM_IN_LDS>
 BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, const BBTile& t, int NB, const BBSeg& s,
-                      long long j, double z) {
+                      long long j, double z, double cnt_cached = 0.0) {
     const int ns = t.nshift;
     const int X = bb_xdim<KIND>(M);
     switch (s.kind) {
@@ -856,7 +856,8 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
         const int bl = (int)bb_umulhi((unsigned)j, M.Tmagic[r]), tt = (int)j - bl * T;
         const bool mut = bl >= ns;
         const double lam = LAM_IN_LDS ? lds[L.lam + NB * tc + j] : bb_exp(z);   // the resident launch keeps the moments pass's table
-        const double cnt = (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
+        // (the resident launch keeps its pairs' counts in LDS: they never change, and the load's latency sat in the G pass)
+        const double cnt = LAM_IN_LDS ? cnt_cached : (double)M.counts[M.cnt_off[r] + t.b0 * T + j];
         const double Gt = (tt > 0 ? lds[L.Dt + tc + tt - 1] : 0.0) - lds[L.Dt + tc + tt];
         double g = cnt - lam + lam * lds[L.invS + tc + tt] * Gt;
         const bool qk = KIND == 3 && M.quirk && !mut;

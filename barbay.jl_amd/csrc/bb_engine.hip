@@ -185,7 +185,8 @@ struct bb_handle {
     std::vector<void*> owned;          // device allocations
     int NB = 0, nthr = 0, nblk = 0, ngeno_blk = 0;
     size_t lds_doubles = 0;            // dynamic LDS of the two-kernel path
-    size_t lds_doubles_p = 0;          // ... of the resident launch (adds the lambda table)
+    size_t lds_doubles_p0 = 0;         // ... of the resident launch (adds the lambda table)
+    size_t lds_doubles_p = 0;          // ... plus the drawn-ahead normals and the cached counts (16 B per pair each)
     long long b_lo = 0, b_hi = 0;      // barcode shard
     long long step = 0;                // host mirror of the device step counter
     int sample = 0;                    // next MC sample inside the current step (split-phase API)
@@ -361,6 +362,7 @@ static int setup_persistent(bb_handle* h) {
         P = (int)((tile_pairs_bound(h) + h->nthr - 1) / h->nthr);
         if (P == 3) P = 4;
         if (P > (h->nthr > 512 ? 2 : 4)) why = "tile too large for the register-resident state";
+        h->lds_doubles_p = h->lds_doubles_p0 + (size_t)4 * P * h->nthr;        // drawn-ahead normals + cached counts
     }
 #ifndef BB_EMU
     if (!why && want) {
@@ -400,7 +402,11 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
         constexpr int PP = decltype(pc)::value;
         std::vector<BBPst<PP>> st((size_t)h->nblk * h->nthr);
         auto cxof = [&](int b) { return BBCtx{h->nthr, b, lds.data() + (size_t)b * (h->lds_doubles_p + 64)}; };
-        for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr); }
+        for (int b = 0; b < h->nblk; ++b) {
+            BBCtx cx = cxof(b);
+            bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr);
+            bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st.data() + (size_t)b * h->nthr, (unsigned long long)h->step);
+        }
         const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
         memset(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4);
         int ok = 1;
@@ -412,6 +418,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
                 BBCtx cx = cxof(b);
                 bbp_sample<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
                 bbp_publish_row(cx, h->M, h->S, L, epoch);
+                bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st.data() + (size_t)b * h->nthr, step + 1);
             }
             for (int g = 0; g < bbp_groups(h->nblk); ++g) { BBCtx cx = cxof(g); bbp_leader_reduce(cx, h->M, h->S, A, L, par, epoch, &ok); }
             for (int b = 0; b < h->nblk; ++b) {
@@ -683,7 +690,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         h->NB = NB;
         h->nthr = nthr;
         h->lds_doubles = need / 8;
-        h->lds_doubles_p = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr, 1).total;
+        h->lds_doubles_p0 = h->lds_doubles_p = (size_t)bb_lds_layout(M.R, M.E, M.kind, M.Ttot, M.nt1, M.K, NB, nthr, 1).total;
         h->nblk = (int)((nbar + NB - 1) / NB);
         h->ngeno_blk = M.G > 0 ? (int)std::min<long long>(((M.G + 1) / 2 + 255) / 256, 64) : 0;
 #ifndef BB_EMU

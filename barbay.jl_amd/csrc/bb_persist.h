@@ -70,6 +70,11 @@ BB_DEV void bb_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v)
     if (a1) base[i0 + 1] = v.y;
 }
 
+// per-thread LDS slots behind the layout's total: the drawn-ahead normals (bbp_draw_ahead), then the pairs' barcode
+// counts (constants of the run; meaningful for loglambda pairs) -- 16 B per pair each
+BB_DEV bb_d2* bbp_eps(BBCtx& cx, const BBLds& L) { return (bb_d2*)(cx.lds + L.total); }
+template <int P> BB_DEV bb_d2* bbp_cnt(BBCtx& cx, const BBLds& L) { return (bb_d2*)(cx.lds + L.total) + P * cx.nthr; }
+
 // ---- prologue: segment table, state into registers -------------------------------------------------
 template <int KIND, int P>
 BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv) {
@@ -98,9 +103,45 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
             st.am[k] = bb_load_pair(S.acc_mu, q.i0, q.a0, q.a1);
             st.ao[k] = bb_load_pair(S.acc_om, q.i0, q.a0, q.a1);
             st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = bb_d2{0.0, 0.0};
+            bb_d2 c{0.0, 0.0};
+            if (q.valid && q.s.kind == SK_L) {
+                const long long base = M.cnt_off[q.s.r] + t.b0 * M.T[q.s.r] + (q.i0 - q.s.lo);
+                if (q.a0) c.x = (double)M.counts[base];
+                if (q.a1) c.y = (double)M.counts[base + 1];
+            }
+            bbp_cnt<P>(cx, L)[k * cx.nthr + tid] = c;
         }
     }
     BB_SYNC(cx);
+}
+
+// ---- next step's standard normals, drawn while the tile waits at the exchange -------------------------------
+// The draw depends only on (seed, latent index, step), never on theta: Philox + Box-Muller (about half of the
+// S pass) run in the exchange's shadow and wait in LDS (16 B per pair, behind the layout's total).  Kept out of
+// line on purpose: inlined into the step loop it raised the kernel's spills from 45 to 143 VGPRs (-25 % steps/s);
+// as a call the allocator treats it as its own region (24 spills, +10 % steps/s over drawing inside the S pass).
+
+template <int KIND, int P>
+#ifdef BB_EMU
+static inline
+#else
+__device__ __attribute__((noinline))
+#endif
+void bbp_draw_ahead(BBCtx& cx, const DevModel& M, const RunArgs& A, int NB, BBPst<P>* stv, unsigned long long step) {
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
+    const BBSeg* sg = (const BBSeg*)(cx.lds + L.seg);
+    bb_d2* eps = bbp_eps(cx, L);
+    BB_PASS(cx, tid) {
+        BBPst<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const BBPair q = bb_pair_cached(sg, st, k);
+            if (!q.valid) continue;
+            double e0, e1;
+            bb_normal_pair(A.seed, (unsigned long long)(q.i0 >> 1), (unsigned)step, 0u, &e0, &e1);
+            eps[k * cx.nthr + tid] = bb_d2{e0, e1};       // read back by the same thread: no barrier needed
+        }
+    }
 }
 
 // ---- first half of a step: draw, stage, moments, publish the tile's K partial rows ---------------------
@@ -124,8 +165,9 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
         for (int k = 0; k < P; ++k) {
             const BBPair q = bb_pair_cached(sg, st, k);
             if (!q.valid) continue;
-            double e0, e1, sp0, sg0, sp1, sg1;
-            bb_normal_pair(A.seed, (unsigned long long)(q.i0 >> 1), (unsigned)step, 0u, &e0, &e1);
+            double sp0, sg0, sp1, sg1;
+            const bb_d2 e = bbp_eps(cx, L)[k * cx.nthr + tid];         // drawn during the previous exchange (bbp_draw_ahead)
+            const double e0 = e.x, e1 = e.y;
             bb_softplus_sigmoid(st.om[k].x, &sp0, &sg0);
             bb_softplus_sigmoid(st.om[k].y, &sp1, &sg1);
             const double z0 = fma(sp0, e0, st.mu[k].x), z1 = fma(sp1, e1, st.mu[k].y);
@@ -326,15 +368,16 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             // the draw is still staged in LDS (tile latents) / came back with the totals (replicated global latents)
             const double* zsrc = q.s.kind >= SK_GS ? lds + L.zgl + (q.s.kind == SK_GLS ? M.nt1 : 0) : lds + q.s.ldsoff;
             double pm, iv, g0 = 0.0, g1 = 0.0;
+            const bb_d2 cnt = bbp_cnt<P>(cx, L)[k * cx.nthr + tid];
             if (q.a0) {
                 const double z0 = zsrc[q.i0 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 - blo, &pm, &iv);
-                g0 = bb_glik<KIND, true>(lds, M, L, t, NB, q.s, q.i0 - q.s.lo, z0) - (z0 - pm) * iv;
+                g0 = bb_glik<KIND, true>(lds, M, L, t, NB, q.s, q.i0 - q.s.lo, z0, cnt.x) - (z0 - pm) * iv;
             }
             if (q.a1) {
                 const double z1 = zsrc[q.i0 + 1 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 + 1 - blo, &pm, &iv);
-                g1 = bb_glik<KIND, true>(lds, M, L, t, NB, q.s, q.i0 + 1 - q.s.lo, z1) - (z1 - pm) * iv;
+                g1 = bb_glik<KIND, true>(lds, M, L, t, NB, q.s, q.i0 + 1 - q.s.lo, z1, cnt.y) - (z1 - pm) * iv;
             }
             if (k == 0) BB_STAMP_W(cx, S, 30);
             const double go0 = fma(g0, st.a[k].x, st.h[k].x), go1 = fma(g1, st.a[k].y, st.h[k].y);
@@ -392,6 +435,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
     BBPst<P> st;
     int* ok_slot = (int*)(bbp_smem + bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1).misc) + 1;
     bbp_prologue<KIND, P>(cx, M, S, A, NB, &st);
+    bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step0);
     int done = 0;
     for (; done < nsteps; ++done) {
         const unsigned long long step = step0 + (unsigned long long)done;
@@ -401,6 +445,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
             const unsigned epoch = (unsigned)(done + 1);
             const int par = (int)(step & 1);
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
+            bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight
             if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce(cx, M, S, A, L, par, epoch, ok_slot);
             bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
             bbp_consume(cx, M, S, A, L, par, epoch, ok_slot);
