@@ -7,5 +7,5 @@ The directory name carries a dot, so import it through the repo-root alias modul
 """
 from . import _capi  # noqa: F401
 from ._capi import BarBayHipError, Engine, load_library  # noqa: F401
-from . import dist, model, sharding, stats, synth, utils, vi  # noqa: F401
+from . import dist, mcmc, model, sharding, stats, synth, utils, vi  # noqa: F401
 from .model import BarBayError  # noqa: F401

@@ -22,7 +22,7 @@ BB_COMM_ID_BYTES = 128
 EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
     "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_run", "bb_run_profiled",
-    "bb_get_posterior", "bb_elbo_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats",
+    "bb_get_posterior", "bb_elbo_grad", "bb_logdensity_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats",
     "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply", "bb_hier_units", "bb_hier_fitness",
 ]
 
@@ -92,6 +92,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.bb_run_profiled.argtypes = [vp, C.c_int64]
     lib.bb_get_posterior.argtypes = [vp, _dp, _dp]
     lib.bb_elbo_grad.argtypes = [vp, _dp, _dp, _dp, C.c_int32, _dp, _dp, _dp]
+    lib.bb_logdensity_grad.argtypes = [vp, _dp, _dp, _dp]
     lib.bb_get_elbo_trace.argtypes = [vp, C.c_int64, C.c_int64, _dp]
     lib.bb_debug_normals.argtypes = [vp, C.c_int64, C.c_uint32, C.c_int64, C.c_int64, _dp]
     lib.bb_get_stats.argtypes = [vp, C.POINTER(bb_stats)]
@@ -293,6 +294,15 @@ class Engine:
         s = bb_stats()
         self._check(self._lib.bb_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in bb_stats._fields_}
+
+    def logdensity_grad(self, z) -> Tuple[float, np.ndarray]:
+        """log p(data, z) and its gradient at a point of the flat latent vector (`bb_logdensity_grad`)."""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        assert z.shape == (self.D,)
+        lp = C.c_double(0.0)
+        g = np.empty(self.D)
+        self._check(self._lib.bb_logdensity_grad(self._h, _ptr(z), C.byref(lp), _ptr(g)))
+        return lp.value, g
 
     def hier_units(self) -> int:
         """Length of the theta_tilde block (0 for the non-hierarchical models)."""

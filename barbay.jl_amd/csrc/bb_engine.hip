@@ -191,6 +191,7 @@ struct bb_handle {
     long long step = 0;                // host mirror of the device step counter
     int sample = 0;                    // next MC sample inside the current step (split-phase API)
     double elbo_const = 0.0;
+    std::vector<double> ld_omega, ld_zero;   // bb_logdensity_grad: constant omega / eps arguments
     double* bak_mu = nullptr;          // bb_elbo_grad: saved parameters
     double* bak_om = nullptr;
     double* eps_buf = nullptr;         // device copy of caller-supplied draws
@@ -1162,6 +1163,21 @@ extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega,
         for (int s = 0; s < S; ++s) v += ev[(size_t)s];
         *elbo = v / S;
     }
+    return BB_OK;
+}
+
+// log-joint density and its gradient at a point of the unconstrained latent space: the ELBO machinery with the
+// draw pinned to the mean (eps = 0) and sigma = softplus(omega) = 1, minus the entropy terms -- what an HMC / NUTS
+// sampler asks of a model (`LogDensityProblems.logdensity_and_gradient`; the reference's src/mcmc.jl:86-160 path)
+extern "C" int bb_logdensity_grad(bb_handle* h, const double* z, double* logp, double* grad) {
+    if (!h || !z) return bb_fail(BB_ERR_INVALID, "null argument");
+    const size_t D = (size_t)h->M.D;
+    const double om1 = 0.54132485461291810;                  // log(e - 1): softplus = 1
+    if (h->ld_omega.size() != D) { h->ld_omega.assign(D, om1); h->ld_zero.assign(D, 0.0); }
+    double elbo = 0.0;
+    int rc = bb_elbo_grad(h, z, h->ld_omega.data(), h->ld_zero.data(), 1, &elbo, grad, nullptr);
+    if (rc) return rc;
+    if (logp) *logp = elbo - 0.5 * (double)D * (1.0 + BB_LOG2PI) - (double)D * log(log1p(exp(om1)));
     return BB_OK;
 }
 

@@ -174,6 +174,13 @@ int bb_get_posterior(bb_handle* h, double* mean, double* sigma);
 int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps,
                  int32_t n_samples, double* elbo, double* grad_mu, double* grad_omega);
 
+/* log p(data, z) of the model (normalisers included) and its gradient at a point z
+ * of the flat latent vector -- the `logdensity_and_gradient` service an HMC / NUTS
+ * sampler needs (the reference's MCMC entry, src/mcmc.jl:86-160, samples the same
+ * Turing model).  logp / grad may be NULL.  Does not touch the variational state.
+ * On a sharded handle the gradient is this shard's part (global blocks replicated). */
+int bb_logdensity_grad(bb_handle* h, const double* z, double* logp, double* grad);
+
 /* ELBO estimates recorded by bb_run (elbo_every > 0): values of steps
  * first_step, first_step + elbo_every, ... ; NaN where not recorded/kept. */
 int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out);

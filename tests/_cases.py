@@ -248,3 +248,19 @@ def case_hier_fitness(lib, name):
                + np.exp(g.normal(mean[lo_lt + u], sigma[lo_lt + u], 400_000)) * g.normal(mean[lo_tt + u], sigma[lo_tt + u], 400_000))
         assert abs(med[u] - np.median(big)) < 6 * 1.2533 * big.std() / np.sqrt(10_000)
         # (std of a lognormal-scaled product is tail-dominated; it is pinned draw for draw above, not statistically)
+
+
+def case_logdensity(lib, name):
+    """bb_logdensity_grad against the literal oracle's log-joint and autograd gradient."""
+    sp = synth(name, seed=6)
+    g = np.random.default_rng(8)
+    with make_engine(sp, lib, seed=1) as e:
+        mu0, om0 = e.get_params()
+        for scale in (0.3, 1.0):
+            z = g.normal(0.0, scale, sp.D)
+            lp, gr = e.logdensity_grad(z)
+            lp2, gr2 = literal.logjoint_and_grad(z, sp)
+            assert abs(lp - lp2) <= 1e-11 * abs(lp2), (lp, lp2)
+            assert np.abs(gr - gr2).max() <= 1e-9 * np.abs(gr2).max()
+        mu1, om1 = e.get_params()
+        assert (mu0 == mu1).all() and (om0 == om1).all()      # the variational state is untouched

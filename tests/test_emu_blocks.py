@@ -92,3 +92,8 @@ def test_ragged_method_neutrals_across_tiles(emu_lib, monkeypatch):
 @pytest.mark.parametrize("name", ["genotype", "replicate_ragged", "multienv_replicate_3d"])
 def test_hier_fitness(emu_lib, name):
     c.case_hier_fitness(emu_lib, name)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
+def test_logdensity_grad(emu_lib, name):
+    c.case_logdensity(emu_lib, name)

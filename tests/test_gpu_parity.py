@@ -178,3 +178,8 @@ def test_ragged_method_pairing(hip_lib, mode):
 @pytest.mark.parametrize("name", ["genotype", "replicate_ragged", "multienv_replicate_3d"])
 def test_hier_fitness(hip_lib, name):
     c.case_hier_fitness(hip_lib, name)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
+def test_logdensity_grad(hip_lib, name):
+    c.case_logdensity(hip_lib, name)
