@@ -186,7 +186,7 @@ struct bb_handle {
     int NB = 0, nthr = 0, nblk = 0, ngeno_blk = 0;
     size_t lds_doubles = 0;            // dynamic LDS of the two-kernel path
     size_t lds_doubles_p0 = 0;         // ... of the resident launch (adds the lambda table)
-    size_t lds_doubles_p = 0;          // ... plus the drawn-ahead normals and the cached counts (16 B per pair each)
+    size_t lds_doubles_p = 0;          // ... plus the drawn-ahead normals and the cached counts (16 + 8 B per pair)
     long long b_lo = 0, b_hi = 0;      // barcode shard
     long long step = 0;                // host mirror of the device step counter
     int sample = 0;                    // next MC sample inside the current step (split-phase API)
@@ -363,7 +363,7 @@ static int setup_persistent(bb_handle* h) {
         P = (int)((tile_pairs_bound(h) + h->nthr - 1) / h->nthr);
         if (P == 3) P = 4;
         if (P > (h->nthr > 512 ? 2 : 4)) why = "tile too large for the register-resident state";
-        h->lds_doubles_p = h->lds_doubles_p0 + (size_t)4 * P * h->nthr;        // drawn-ahead normals + cached counts
+        h->lds_doubles_p = h->lds_doubles_p0 + (size_t)3 * P * h->nthr;        // drawn-ahead normals (16 B / pair) + cached counts (8 B)
     }
 #ifndef BB_EMU
     if (!why && want) {

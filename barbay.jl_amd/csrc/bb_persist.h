@@ -70,10 +70,11 @@ BB_DEV void bb_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v)
     if (a1) base[i0 + 1] = v.y;
 }
 
-// per-thread LDS slots behind the layout's total: the drawn-ahead normals (bbp_draw_ahead), then the pairs' barcode
-// counts (constants of the run; meaningful for loglambda pairs) -- 16 B per pair each
+// per-thread LDS slots behind the layout's total: the drawn-ahead normals (bbp_draw_ahead, 16 B per pair), then the
+// pairs' barcode counts (constants of the run; meaningful for loglambda pairs; 8 B per pair)
+struct alignas(8) bb_u2 { unsigned x, y; };
 BB_DEV bb_d2* bbp_eps(BBCtx& cx, const BBLds& L) { return (bb_d2*)(cx.lds + L.total); }
-template <int P> BB_DEV bb_d2* bbp_cnt(BBCtx& cx, const BBLds& L) { return (bb_d2*)(cx.lds + L.total) + P * cx.nthr; }
+template <int P> BB_DEV bb_u2* bbp_cnt(BBCtx& cx, const BBLds& L) { return (bb_u2*)(cx.lds + L.total + 2 * P * cx.nthr); }
 
 // ---- prologue: segment table, state into registers -------------------------------------------------
 template <int KIND, int P>
@@ -103,11 +104,11 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
             st.am[k] = bb_load_pair(S.acc_mu, q.i0, q.a0, q.a1);
             st.ao[k] = bb_load_pair(S.acc_om, q.i0, q.a0, q.a1);
             st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = bb_d2{0.0, 0.0};
-            bb_d2 c{0.0, 0.0};
+            bb_u2 c{0u, 0u};
             if (q.valid && q.s.kind == SK_L) {
                 const long long base = M.cnt_off[q.s.r] + t.b0 * M.T[q.s.r] + (q.i0 - q.s.lo);
-                if (q.a0) c.x = (double)M.counts[base];
-                if (q.a1) c.y = (double)M.counts[base + 1];
+                if (q.a0) c.x = M.counts[base];
+                if (q.a1) c.y = M.counts[base + 1];
             }
             bbp_cnt<P>(cx, L)[k * cx.nthr + tid] = c;
         }
@@ -368,7 +369,8 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             // the draw is still staged in LDS (tile latents) / came back with the totals (replicated global latents)
             const double* zsrc = q.s.kind >= SK_GS ? lds + L.zgl + (q.s.kind == SK_GLS ? M.nt1 : 0) : lds + q.s.ldsoff;
             double pm, iv, g0 = 0.0, g1 = 0.0;
-            const bb_d2 cnt = bbp_cnt<P>(cx, L)[k * cx.nthr + tid];
+            const bb_u2 cu = bbp_cnt<P>(cx, L)[k * cx.nthr + tid];
+            const bb_d2 cnt{(double)cu.x, (double)cu.y};
             if (q.a0) {
                 const double z0 = zsrc[q.i0 - q.s.lo];
                 bb_prior_of(M, q.s.blk, q.i0 - blo, &pm, &iv);

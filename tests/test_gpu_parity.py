@@ -118,8 +118,8 @@ def test_persistent_equals_two_kernel(hip_lib, name):
 
 
 def test_persistent_two_pairs_per_thread(hip_lib, monkeypatch):
-    monkeypatch.setenv("BB_TUNE_NB", "120")
-    monkeypatch.setenv("BB_TUNE_NTHR", "1024")
+    monkeypatch.setenv("BB_TUNE_NB", "60")            # 60 barcodes x 13 pairs on 512 threads: P = 2
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
     c.case_persistent_equals_two_kernel(hip_lib, "replicate_ragged")
 
 
