@@ -318,19 +318,17 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr) {
         }
     }
     switch (kind * 10 + P) {   // <= 8 waves per CU: 256 VGPRs per lane, more pairs per thread
-    case 1: return k_persist<0, 1, 512>;   case 2: return k_persist<0, 2, 512>;   case 4: return k_persist<0, 4, 512>;
-    case 11: return k_persist<1, 1, 512>;  case 12: return k_persist<1, 2, 512>;  case 14: return k_persist<1, 4, 512>;
-    case 31: return k_persist<3, 1, 512>;  case 32: return k_persist<3, 2, 512>;  case 34: return k_persist<3, 4, 512>;
-    case 41: return k_persist<4, 1, 512>;  case 42: return k_persist<4, 2, 512>;  case 44: return k_persist<4, 4, 512>;
+    case 1: return k_persist<0, 1, 512>;   case 2: return k_persist<0, 2, 512>;   case 3: return k_persist<0, 3, 512>;   case 4: return k_persist<0, 4, 512>;
+    case 11: return k_persist<1, 1, 512>;  case 12: return k_persist<1, 2, 512>;  case 13: return k_persist<1, 3, 512>;  case 14: return k_persist<1, 4, 512>;
+    case 31: return k_persist<3, 1, 512>;  case 32: return k_persist<3, 2, 512>;  case 33: return k_persist<3, 3, 512>;  case 34: return k_persist<3, 4, 512>;
+    case 41: return k_persist<4, 1, 512>;  case 42: return k_persist<4, 2, 512>;  case 43: return k_persist<4, 3, 512>;  case 44: return k_persist<4, 4, 512>;
     default: return nullptr;
     }
 }
 #endif
 
 // pairs a tile can hold: every segment contributes count/2 + 1 at most
-static long long tile_pairs_bound(const bb_handle* h) {
-    const DevModel& M = h->M;
-    const long long NB = h->NB;
+static long long tile_pairs_bound(const DevModel& M, long long NB) {
     long long p = 0;
     for (int r = 0; r < M.R; ++r) p += NB * M.T[r] / 2 + 1;
     if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
@@ -360,8 +358,8 @@ static int setup_persistent(bb_handle* h) {
     else if (h->M.kind == BB_MODEL_GENOTYPE) why = "genotype model (second exchange per step)";
     int P = 0;
     if (!why) {
-        P = (int)((tile_pairs_bound(h) + h->nthr - 1) / h->nthr);
-        if (P == 3) P = 4;
+        P = (int)((tile_pairs_bound(h->M, h->NB) + h->nthr - 1) / h->nthr);
+        if (P == 3 && h->nthr > 512) P = 4;      // (no 3-pair instance at 1024 threads; 4 is refused just below)
         if (P > (h->nthr > 512 ? 2 : 4)) why = "tile too large for the register-resident state";
         h->lds_doubles_p = h->lds_doubles_p0 + (size_t)3 * P * h->nthr;        // drawn-ahead normals (16 B / pair) + cached counts (8 B)
     }
@@ -435,6 +433,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     auto byP = [&](auto kindc) {
         if (P == 1) run(kindc, std::integral_constant<int, 1>{});
         else if (P == 2) run(kindc, std::integral_constant<int, 2>{});
+        else if (P == 3) run(kindc, std::integral_constant<int, 3>{});
         else run(kindc, std::integral_constant<int, 4>{});
     };
     switch (h->M.kind) {
@@ -675,7 +674,8 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         for (;;) {
             const int per_mutant = M.kind == 0 ? 2 : (M.kind == 1 ? 2 * M.E : (M.kind == 2 ? 3 : (M.kind == 3 ? 1 + 3 * M.R : M.E * (1 + 3 * M.R))));
             const long long pairs = (long long)NB * (M.Ttot + per_mutant) / 2;   // one pair of latents per thread is the sweet spot
-            // > 1 pair per thread: 512 threads (256-VGPR budget, up to 4 pairs) beat 1024 threads with spills (C3: 23.3k vs 17.0k steps/s)
+            // > 1 pair per thread: 512 threads (256-VGPR budget, up to 4 pairs) beat 1024 threads with spills (C3: 28.8k vs 18.8k steps/s)
+            // (768 threads x 2 pairs was tried for C3: 138 spills at 168 VGPRs, 23.0k vs 28.8k steps/s for 512 x 3)
             nthr = pairs > 2048 ? 1024 : (pairs > 1024 ? 512 : (pairs > 512 ? 1024 : (pairs > 256 ? 512 : 256)));
             if ((ev = getenv("BB_TUNE_NTHR")) && atoi(ev) >= 64) nthr = atoi(ev) / 64 * 64;
             while (nthr < maxT) nthr <<= 1;

@@ -122,26 +122,36 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
 // line on purpose: inlined into the step loop it raised the kernel's spills from 45 to 143 VGPRs (-25 % steps/s);
 // as a call the allocator treats it as its own region (24 spills, +10 % steps/s over drawing inside the S pass).
 
-template <int KIND, int P>
+// (the pairs' indices travel BY VALUE: handing the callee a pointer to the register state would pin that whole
+// struct in scratch memory for the entire launch)
+template <int P> struct BBPairIdx { long long i0[P]; int meta[P]; };
+
+template <int P>
 #ifdef BB_EMU
 static inline
 #else
 __device__ __attribute__((noinline))
 #endif
-void bbp_draw_ahead(BBCtx& cx, const DevModel& M, const RunArgs& A, int NB, BBPst<P>* stv, unsigned long long step) {
+void bbp_draw_ahead_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsigned step, BBPairIdx<P> ix) {
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        if (!((ix.meta[k] >> 10) & 1)) continue;          // no pair in this slot
+        double e0, e1;
+        bb_normal_pair(seed, (unsigned long long)(ix.i0[k] >> 1), step, 0u, &e0, &e1);
+        eps[k * nthr + tid] = bb_d2{e0, e1};              // read back by the same thread: no barrier needed
+    }
+}
+
+template <int KIND, int P>
+BB_DEV void bbp_draw_ahead(BBCtx& cx, const DevModel& M, const RunArgs& A, int NB, BBPst<P>* stv, unsigned long long step) {
     const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
-    const BBSeg* sg = (const BBSeg*)(cx.lds + L.seg);
     bb_d2* eps = bbp_eps(cx, L);
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
+        BBPairIdx<P> ix;
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const BBPair q = bb_pair_cached(sg, st, k);
-            if (!q.valid) continue;
-            double e0, e1;
-            bb_normal_pair(A.seed, (unsigned long long)(q.i0 >> 1), (unsigned)step, 0u, &e0, &e1);
-            eps[k * cx.nthr + tid] = bb_d2{e0, e1};       // read back by the same thread: no barrier needed
-        }
+        for (int k = 0; k < P; ++k) { ix.i0[k] = st.i0[k]; ix.meta[k] = st.meta[k]; }
+        bbp_draw_ahead_call<P>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
     }
 }
 

@@ -22,9 +22,10 @@ import barbay_jl_amd as bb  # noqa: E402
 from barbay_jl_amd import _capi, synth  # noqa: E402
 
 lib = _capi.load_library(out)
-wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42)
+WL = os.environ.get("WL", "fitness_normal")          # or replicate_fitness_normal / multienv_fitness_normal (C3 / C4 sizes)
+wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42) if WL == "fitness_normal" else getattr(synth, WL)()
 mode = int(os.environ.get("MODE", 1))
-e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, steps_per_graph=-1, launch_mode=mode, optimizer=os.environ.get("OPT", "TruncatedADAGrad"), _lib=lib)
+e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=42, steps_per_graph=-1, launch_mode=mode, optimizer=os.environ.get("OPT", "TruncatedADAGrad"), _lib=lib)
 e.run(21)
 st = e.stamps().astype(np.int64)
 names = {1: "S draw", 2: "E tables", 3: "M accumulate", 4: "M reduce", 5: "row_sum", 6: "write partials",
