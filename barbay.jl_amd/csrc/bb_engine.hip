@@ -1296,7 +1296,7 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->avg_update_ms = h->avg_update_ms;
     s->n_blocks = h->nblk;
     s->block_threads = h->nthr;
-    s->lds_bytes = (int32_t)(h->lds_doubles * 8);
+    s->lds_bytes = (int32_t)((h->persist_P > 0 ? h->lds_doubles_p : h->lds_doubles) * 8);
     s->persistent_pairs = h->persist_P;
     s->launches_last_run = h->launches_last_run;
     return BB_OK;

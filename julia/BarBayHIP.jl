@@ -67,7 +67,11 @@ check(rc) = rc == 0 || error("barbay_hip: " * unsafe_string(ccall((:bb_last_erro
 # what advi_to_df needs from `q`
 struct Dist; m::Vector{Float64}; σ::Vector{Float64}; end
 struct Transform; ranges_out::Vector{UnitRange{Int}}; end
-struct Posterior; dist::Dist; transform::Transform; end
+struct Posterior
+    dist::Dist
+    transform::Transform
+    hier::Union{Nothing,NamedTuple}     # device-side `process_hierarchical_samples!` result (median, std per θ̃ unit), if any
+end
 
 const KIND = Dict("fitness_normal" => 0, "multienv_fitness_normal" => 1, "genotype_fitness_normal" => 2,
                   "replicate_fitness_normal" => 3, "multienv_replicate_fitness_normal" => 4)
@@ -86,7 +90,7 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
             samples_per_step::Int=1, max_iters::Int=10_000,
             optimizer::Symbol=:TruncatedADAGrad, eta=0.1, tau=40.0, n=100, pre=1.0, post=0.9,
             priors::Dict{Symbol,<:Any}=Dict{Symbol,Any}(), envs=nothing, genotypes=nothing,
-            seed::Integer=0, device::Integer=0)
+            seed::Integer=0, device::Integer=0, hier_samples::Integer=10_000)
     mats = R isa Vector ? R : (ndims(R) == 3 ? [R[:, :, r] for r in axes(R, 3)] : [R])
     tots = n_t isa Vector{<:Vector} ? n_t : (ndims(n_t) == 2 ? [n_t[:, r] for r in axes(n_t, 2)] : [n_t])
     n_time = Int32[size(m, 1) for m in mats]
@@ -126,7 +130,15 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
         nb = Ref{Int32}(0)
         check(ccall((:bb_get_layout, LIB), Cint, (Ptr{Cvoid}, Ptr{bb_block_range}, Ref{Int32}), h[], blocks, nb))
         ranges = [Int(b.lo)+1:Int(b.hi) for b in blocks[1:nb[]]]
-        return Posterior(Dist(m, s), Transform(ranges))
+        hier = nothing
+        nu = ccall((:bb_hier_units, LIB), Int64, (Ptr{Cvoid},), h[])
+        if nu > 0 && hier_samples > 0          # src/utils.jl:1284-1343 on the device: 10 000 draws per unit, median + std
+            med, sd = Vector{Float64}(undef, nu), Vector{Float64}(undef, nu)
+            check(ccall((:bb_hier_fitness, LIB), Cint, (Ptr{Cvoid}, Int32, UInt64, Ptr{Float64}, Ptr{Float64}),
+                        h[], hier_samples, seed, med, sd))
+            hier = (n_samples=hier_samples, median=med, std=sd)
+        end
+        return Posterior(Dist(m, s), Transform(ranges), hier)
     finally
         ccall((:bb_destroy, LIB), Cvoid, (Ptr{Cvoid},), h[])
     end
