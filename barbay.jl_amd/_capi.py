@@ -18,12 +18,14 @@ BB_MODEL = {"fitness": 0, "multienv": 1, "genotype": 2, "replicate": 3, "multien
 BB_OPT_TRUNCATED_ADAGRAD = 0
 BB_OPT_DECAYED_ADAGRAD = 1
 BB_COMM_ID_BYTES = 128
+BB_P2P_HANDLE_BYTES = 64
+BB_ERR_UNSUPPORTED = -4
 
 EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
     "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_run", "bb_run_profiled",
     "bb_get_posterior", "bb_elbo_grad", "bb_logdensity_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats",
-    "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply", "bb_hier_units", "bb_hier_fitness",
+    "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply", "bb_hier_units", "bb_hier_fitness", "bb_p2p_export", "bb_p2p_import", "bb_p2p_selftest", "bb_p2p_enable",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -101,6 +103,10 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.bb_comm_init.argtypes = [vp, C.c_void_p]
     lib.bb_step_moments.argtypes = [vp, _dp]
     lib.bb_step_apply.argtypes = [vp, _dp]
+    lib.bb_p2p_export.argtypes = [vp, C.c_void_p]
+    lib.bb_p2p_import.argtypes = [vp, C.c_void_p]
+    lib.bb_p2p_selftest.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.bb_p2p_enable.argtypes = [vp, C.c_int32]
     lib.bb_hier_units.argtypes = [vp]
     lib.bb_hier_units.restype = C.c_int64
     lib.bb_hier_fitness.argtypes = [vp, C.c_int32, C.c_uint64, _dp, _dp]
@@ -314,6 +320,31 @@ class Engine:
         med, sd = np.empty(n), np.empty(n)
         self._check(self._lib.bb_hier_fitness(self._h, n_samples, seed, _ptr(med), _ptr(sd)))
         return med, sd
+
+    # ---- cross-GPU leg of the resident launch (include/barbay_hip.h, bb_p2p_*) ----
+    def p2p_export(self) -> bytes:
+        buf = C.create_string_buffer(BB_P2P_HANDLE_BYTES)
+        self._check(self._lib.bb_p2p_export(self._h, buf))
+        return buf.raw
+
+    def p2p_import(self, handles: Sequence[bytes]):
+        blob = b"".join(handles)
+        assert len(blob) == BB_P2P_HANDLE_BYTES * len(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self._lib.bb_p2p_import(self._h, buf))
+
+    def p2p_selftest(self) -> bool:
+        ok = C.c_int32(0)
+        self._check(self._lib.bb_p2p_selftest(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+    def p2p_enable(self, on: bool) -> bool:
+        """True if the resident launch is now (on) / no longer (off) in use; False if this shard cannot use it."""
+        rc = self._lib.bb_p2p_enable(self._h, 1 if on else 0)
+        if rc == BB_ERR_UNSUPPORTED:
+            return False
+        self._check(rc)
+        return True
 
     def make_comm_id(self) -> bytes:
         buf = C.create_string_buffer(BB_COMM_ID_BYTES)

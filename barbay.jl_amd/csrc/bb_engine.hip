@@ -137,6 +137,20 @@ __global__ void __launch_bounds__(1024) k_hier(HierArgs H) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_hier(cx, H, (int)gridDim.x);
 }
+// transport probe of the cross-GPU leg: this rank's token into every peer's inbox, then every peer's token here
+__global__ void __launch_bounds__(64) k_p2p_probe_seq(DevState S, int rank, int world, size_t probe_words_off, unsigned seq, unsigned* result) {
+    const int r = threadIdx.x;
+    if (r < world) {
+        unsigned* out = S.xout_rdy[r] + probe_words_off + 32 * rank;
+        __hip_atomic_store(out, 0xB0000000u | (seq << 8) | (unsigned)rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned* in = S.xout_rdy[rank] + probe_words_off + 32 * r;
+        const unsigned want = 0xB0000000u | (seq << 8) | (unsigned)r;
+        unsigned seen = 0, spins = 0;
+        while ((seen = __hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != want && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+        result[r] = seen == want ? 1u : 0u;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_normals(unsigned long long seed, unsigned step, unsigned stream, long long lo,
                                                  long long hi, double* out) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
@@ -192,6 +206,12 @@ struct bb_handle {
     int sample = 0;                    // next MC sample inside the current step (split-phase API)
     double elbo_const = 0.0;
     std::vector<double> ld_omega, ld_zero;   // bb_logdensity_grad: constant omega / eps arguments
+    // cross-GPU leg of the resident launch (bb_p2p_*)
+    void* p2p_inbox = nullptr;               // this rank's inbox (fine-grained device memory)
+    size_t p2p_rows_bytes = 0, p2p_bytes = 0;
+    void* p2p_peer[BB_MAX_WORLD] = {};       // peers' inboxes as mapped here
+    bool p2p_ready = false, p2p_on = false;
+    unsigned p2p_seq = 0;                    // probe sequence number (tokens only ever grow)
     double* bak_mu = nullptr;          // bb_elbo_grad: saved parameters
     double* bak_om = nullptr;
     double* eps_buf = nullptr;         // device copy of caller-supplied draws
@@ -307,7 +327,20 @@ static int launch_check();
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_EMU
 typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, RunArgs, int, unsigned long long, int);
-static bb_persist_kernel persist_kernel(int kind, int P, int nthr) {
+static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false) {
+    if (xg) {                  // sharded tiles are small: one pair per thread only
+        if (P != 1) return nullptr;
+        if (nthr > 512) switch (kind) {
+            case 0: return k_persist<0, 1, 1024, true>;  case 1: return k_persist<1, 1, 1024, true>;
+            case 3: return k_persist<3, 1, 1024, true>;  case 4: return k_persist<4, 1, 1024, true>;
+            default: return nullptr;
+        }
+        switch (kind) {
+        case 0: return k_persist<0, 1, 512, true>;  case 1: return k_persist<1, 1, 512, true>;
+        case 3: return k_persist<3, 1, 512, true>;  case 4: return k_persist<4, 1, 512, true>;
+        default: return nullptr;
+        }
+    }
     if (nthr > 512) {          // 16 waves per CU: 128 VGPRs per lane
         switch (kind * 10 + P) {
         case 1: return k_persist<0, 1, 1024>;   case 2: return k_persist<0, 2, 1024>;
@@ -353,7 +386,8 @@ static int setup_persistent(bb_handle* h) {
     const bool want = h->o.launch_mode != 1 && !(ev && atoi(ev) > 0 && h->o.launch_mode == 0);
     const char* why = nullptr;
     if (h->o.samples_per_step != 1) why = "samples_per_step != 1";
-    else if (h->o.world_size != 1 || h->force_reduce) why = "sharded run";
+    else if (h->force_reduce || (h->o.world_size != 1 && !h->p2p_on)) why = "sharded run";
+    else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";
     else if (h->o.elbo_every != 0) why = "ELBO recording is on";
     else if (h->M.kind == BB_MODEL_GENOTYPE) why = "genotype model (second exchange per step)";
     int P = 0;
@@ -361,11 +395,12 @@ static int setup_persistent(bb_handle* h) {
         P = (int)((tile_pairs_bound(h->M, h->NB) + h->nthr - 1) / h->nthr);
         if (P == 3 && h->nthr > 512) P = 4;      // (no 3-pair instance at 1024 threads; 4 is refused just below)
         if (P > (h->nthr > 512 ? 2 : 4)) why = "tile too large for the register-resident state";
+        if (h->p2p_on && P != 1) why = "sharded resident launch holds one pair per thread";
         h->lds_doubles_p = h->lds_doubles_p0 + (size_t)3 * P * h->nthr;        // drawn-ahead normals (16 B / pair) + cached counts (8 B)
     }
 #ifndef BB_EMU
     if (!why && want) {
-        bb_persist_kernel k = persist_kernel(h->M.kind, P, h->nthr);
+        bb_persist_kernel k = persist_kernel(h->M.kind, P, h->nthr, h->p2p_on);
         const int lds = (int)(h->lds_doubles_p * 8);
         if (lds > 160 * 1024) why = "tile does not fit LDS with the lambda table";
         else if (!k) why = "no kernel instance";
@@ -390,61 +425,127 @@ static int setup_persistent(bb_handle* h) {
     return 0;
 }
 
-static int launch_persistent(bb_handle* h, long long nsteps) {
-    RunArgs A = make_args(h, h->step, 0, 1, true, false);
-    int rc = 0;
 #ifdef BB_EMU
-    const int P = h->persist_P;
-    std::vector<double> lds((size_t)h->nblk * (h->lds_doubles_p + 64));
-    auto run = [&](auto kindc, auto pc) {
-        constexpr int KIND = decltype(kindc)::value;
-        constexpr int PP = decltype(pc)::value;
-        std::vector<BBPst<PP>> st((size_t)h->nblk * h->nthr);
-        auto cxof = [&](int b) { return BBCtx{h->nthr, b, lds.data() + (size_t)b * (h->lds_doubles_p + 64)}; };
+// Host emulation of the resident launch, phase by phase so that several handles (the ranks of a sharded run, all in
+// this process) can be stepped in lock step: phase 0 prologue, 1 sample + publish + draw-ahead, 2 leaders,
+// 3 consume + update, 4 epilogue.
+struct EmuPersist {
+    bb_handle* h = nullptr;
+    std::vector<double> lds;
+    std::vector<unsigned char> st;      // BBPst<P>[nblk * nthr]
+    RunArgs A;
+    int ok = 1;
+};
+
+template <int KIND, int PP>
+static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long nsteps) {
+    bb_handle* h = E.h;
+    const RunArgs& A = E.A;
+    BBPst<PP>* st = (BBPst<PP>*)E.st.data();
+    auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64)}; };
+    const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
+    const unsigned long long step = (unsigned long long)(h->step + it);
+    const unsigned epoch = (unsigned)(it + 1), abs_epoch = (unsigned)(step + 1);
+    const int par = (int)(step & 1);
+    const bool xg = h->p2p_on;
+    if (phase == 0) {
         for (int b = 0; b < h->nblk; ++b) {
             BBCtx cx = cxof(b);
-            bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr);
-            bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st.data() + (size_t)b * h->nthr, (unsigned long long)h->step);
+            bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr);
+            bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st + (size_t)b * h->nthr, (unsigned long long)h->step);
         }
-        const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
         memset(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4);
-        int ok = 1;
-        for (long long it = 0; it < nsteps; ++it) {
-            const unsigned long long step = (unsigned long long)(h->step + it);
-            const unsigned epoch = (unsigned)(it + 1);
-            const int par = (int)(step & 1);
-            for (int b = 0; b < h->nblk; ++b) {
-                BBCtx cx = cxof(b);
-                bbp_sample<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
-                bbp_publish_row(cx, h->M, h->S, L, epoch);
-                bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st.data() + (size_t)b * h->nthr, step + 1);
-            }
-            for (int g = 0; g < bbp_groups(h->nblk); ++g) { BBCtx cx = cxof(g); bbp_leader_reduce(cx, h->M, h->S, A, L, par, epoch, &ok); }
-            for (int b = 0; b < h->nblk; ++b) {
-                BBCtx cx = cxof(b);
-                bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
-                bbp_consume(cx, h->M, h->S, A, L, par, epoch, &ok);
-                bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, step);
-            }
+    } else if (phase == 1) {
+        for (int b = 0; b < h->nblk; ++b) {
+            BBCtx cx = cxof(b);
+            bbp_sample<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
+            bbp_publish_row(cx, h->M, h->S, L, epoch);
+            bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st + (size_t)b * h->nthr, step + 1);
         }
-        if (!ok) rc = bb_fail(BB_ERR_DEVICE, "emulated exchange found a missing row");
-        for (int b = 0; b < h->nblk; ++b) { BBCtx cx = cxof(b); bbp_epilogue<KIND, PP>(cx, h->M, h->S, A, h->NB, st.data() + (size_t)b * h->nthr, (unsigned long long)(h->step + nsteps)); }
-    };
+    } else if (phase == 2) {
+        for (int g = 0; g < bbp_groups(h->nblk); ++g) {
+            BBCtx cx = cxof(g);
+            if (xg) bbp_leader_reduce<true>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
+            else bbp_leader_reduce<false>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
+        }
+    } else if (phase == 3) {
+        for (int b = 0; b < h->nblk; ++b) {
+            BBCtx cx = cxof(b);
+            bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
+            if (xg) bbp_consume<true>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
+            else bbp_consume<false>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
+            bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
+        }
+    } else {
+        for (int b = 0; b < h->nblk; ++b) {
+            BBCtx cx = cxof(b);
+            bbp_epilogue<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, (unsigned long long)(h->step + nsteps));
+        }
+    }
+}
+
+static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long long nsteps) {
     auto byP = [&](auto kindc) {
-        if (P == 1) run(kindc, std::integral_constant<int, 1>{});
-        else if (P == 2) run(kindc, std::integral_constant<int, 2>{});
-        else if (P == 3) run(kindc, std::integral_constant<int, 3>{});
-        else run(kindc, std::integral_constant<int, 4>{});
+        constexpr int KIND = decltype(kindc)::value;
+        switch (E.h->persist_P) {
+        case 1: emu_persist_phase<KIND, 1>(E, phase, it, nsteps); break;
+        case 2: emu_persist_phase<KIND, 2>(E, phase, it, nsteps); break;
+        case 3: emu_persist_phase<KIND, 3>(E, phase, it, nsteps); break;
+        default: emu_persist_phase<KIND, 4>(E, phase, it, nsteps);
+        }
     };
-    switch (h->M.kind) {
+    switch (E.h->M.kind) {
     case 0: byP(std::integral_constant<int, 0>{}); break;
     case 1: byP(std::integral_constant<int, 1>{}); break;
     case 3: byP(std::integral_constant<int, 3>{}); break;
     default: byP(std::integral_constant<int, 4>{});
     }
-    h->step += nsteps;
+}
+
+static size_t emu_pst_bytes(int P) {
+    return P == 1 ? sizeof(BBPst<1>) : (P == 2 ? sizeof(BBPst<2>) : (P == 3 ? sizeof(BBPst<3>) : sizeof(BBPst<4>)));
+}
+
+static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
+    std::vector<EmuPersist> es((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        bb_handle* h = hs[i];
+        es[i].h = h;
+        es[i].A = make_args(h, h->step, 0, 1, true, false);
+        es[i].lds.assign((size_t)h->nblk * (h->lds_doubles_p + 64), 0.0);
+        es[i].st.assign((size_t)h->nblk * h->nthr * emu_pst_bytes(h->persist_P), 0);
+        emu_persist_dispatch(es[i], 0, 0, nsteps);
+    }
+    for (long long it = 0; it < nsteps; ++it)
+        for (int phase = 1; phase <= 3; ++phase)
+            for (int i = 0; i < n; ++i) emu_persist_dispatch(es[i], phase, it, nsteps);
+    int rc = 0;
+    for (int i = 0; i < n; ++i) {
+        emu_persist_dispatch(es[i], 4, 0, nsteps);
+        if (!es[i].ok) rc = bb_fail(BB_ERR_DEVICE, "emulated exchange found a missing row");
+        hs[i]->step += nsteps;
+    }
+    return rc;
+}
+
+// test hook of the emulation build: the ranks of a sharded resident run, stepped in lock step in one process
+extern "C" int bb_emu_run_group(bb_handle** hs, int32_t n, int64_t nsteps) {
+    if (!hs || n < 1 || nsteps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!hs[i] || hs[i]->persist_P == 0) return bb_fail(BB_ERR_INVALID, "handle %d has no resident launch", i);
+    return emu_run_group(hs, n, nsteps);
+}
+#endif
+
+static int launch_persistent(bb_handle* h, long long nsteps) {
+    RunArgs A = make_args(h, h->step, 0, 1, true, false);
+    int rc = 0;
+#ifdef BB_EMU
+    (void)A;
+    if (h->p2p_on) return bb_fail(BB_ERR_UNSUPPORTED, "emulation: step the ranks of a sharded resident run with bb_emu_run_group");
+    rc = emu_run_group(&h, 1, nsteps);
 #else
-    bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P, h->nthr);
+    bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
     while (nsteps > 0 && !rc) {
         const int n = (int)std::min<long long>(nsteps, 4096);
         BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
@@ -752,6 +853,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     return BB_OK;
 }
 
+static void p2p_release(bb_handle* h);
 extern "C" void bb_destroy(bb_handle* h) {
     if (!h) return;
 #ifndef BB_EMU
@@ -761,6 +863,7 @@ extern "C" void bb_destroy(bb_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
 #endif
+    p2p_release(h);
     for (void* p : h->owned) dfree(p);
     if (h->eps_buf) dfree(h->eps_buf);
     if (h->dbg_buf) dfree(h->dbg_buf);
@@ -787,6 +890,8 @@ static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, 
     memset(&A, 0, sizeof A);
     A.b_lo = h->b_lo;
     A.b_hi = h->b_hi;
+    A.rank = h->o.rank;
+    A.world = h->o.world_size;
     A.nblk = h->nblk;
     A.par = (int)(step & 1);
     A.sample = sample;
@@ -1229,6 +1334,135 @@ extern "C" int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n) {
     int rc = dsync(h->stream);
     if (rc) return rc;
     return d2h(out, h->S.stamps, (size_t)std::min(n, have) * 8, h->stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-GPU leg of the resident launch: inbox, IPC handles, transport probe, switch
+// ------------------------------------------------------------------------------------------------
+static size_t p2p_rows_bytes(const bb_handle* h) {
+    const size_t n = (size_t)2 * h->o.world_size * 8 * (size_t)(h->M.K + 2 * h->M.nt1) * 8;
+    return (n + 255) & ~(size_t)255;
+}
+// ready words: [2][world][8] lines of 128 B, then the probe's [world] lines
+static size_t p2p_probe_words_off(const bb_handle* h) { return (size_t)32 * 2 * h->o.world_size * 8; }
+
+static void p2p_release(bb_handle* h) {
+#ifndef BB_EMU
+    for (int r = 0; r < BB_MAX_WORLD; ++r)
+        if (h->p2p_peer[r] && r != h->o.rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
+    if (h->p2p_inbox) (void)hipFree(h->p2p_inbox);
+#else
+    if (h->p2p_inbox) free(h->p2p_inbox);
+#endif
+    h->p2p_inbox = nullptr;
+    h->p2p_ready = h->p2p_on = false;
+}
+
+extern "C" int bb_p2p_export(bb_handle* h, void* handle_out) {
+    if (!h || !handle_out) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (h->o.world_size < 2) return bb_fail(BB_ERR_INVALID, "bb_p2p_export needs a sharded handle (world_size > 1)");
+    if (h->o.world_size > BB_MAX_WORLD) return bb_fail(BB_ERR_UNSUPPORTED, "at most %d ranks", BB_MAX_WORLD);
+    if (h->M.kind == BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_UNSUPPORTED, "the genotype model has no resident launch");
+    memset(handle_out, 0, BB_P2P_HANDLE_BYTES);
+    if (!h->p2p_inbox) {
+        h->p2p_rows_bytes = p2p_rows_bytes(h);
+        h->p2p_bytes = h->p2p_rows_bytes + (p2p_probe_words_off(h) + (size_t)32 * h->o.world_size) * 4;
+#ifdef BB_EMU
+        h->p2p_inbox = calloc(1, h->p2p_bytes);
+        if (!h->p2p_inbox) return bb_fail(BB_ERR_DEVICE, "out of memory");
+#else
+        // fine-grained: remote stores and local polls must meet in memory, not in either side's L2
+        BB_HIP(hipExtMallocWithFlags(&h->p2p_inbox, h->p2p_bytes, hipDeviceMallocFinegrained));
+        BB_HIP(hipMemsetAsync(h->p2p_inbox, 0, h->p2p_bytes, h->stream));
+        BB_HIP(hipStreamSynchronize(h->stream));
+#endif
+    }
+#ifdef BB_EMU
+    memcpy(handle_out, &h->p2p_inbox, sizeof(void*));
+#else
+    static_assert(sizeof(hipIpcMemHandle_t) <= BB_P2P_HANDLE_BYTES, "IPC handle does not fit");
+    hipIpcMemHandle_t hnd;
+    BB_HIP(hipIpcGetMemHandle(&hnd, h->p2p_inbox));
+    memcpy(handle_out, &hnd, sizeof hnd);
+#endif
+    return BB_OK;
+}
+
+extern "C" int bb_p2p_import(bb_handle* h, const void* handles) {
+    if (!h || !handles) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->p2p_inbox) return bb_fail(BB_ERR_INVALID, "bb_p2p_export comes first");
+    const int W = h->o.world_size;
+    for (int r = 0; r < W; ++r) {
+        void* base = nullptr;
+        if (r == h->o.rank) base = h->p2p_inbox;
+        else {
+            const char* src = (const char*)handles + (size_t)r * BB_P2P_HANDLE_BYTES;
+#ifdef BB_EMU
+            memcpy(&base, src, sizeof(void*));
+#else
+            if (!h->p2p_peer[r]) {
+                hipIpcMemHandle_t hnd;
+                memcpy(&hnd, src, sizeof hnd);
+                BB_HIP(hipIpcOpenMemHandle(&base, hnd, hipIpcMemLazyEnablePeerAccess));
+            } else base = h->p2p_peer[r];
+#endif
+            if (!base) return bb_fail(BB_ERR_COMM, "rank %d's inbox did not map", r);
+        }
+        h->p2p_peer[r] = base;
+        h->S.xout[r] = (double*)base;
+        h->S.xout_rdy[r] = (unsigned*)((char*)base + h->p2p_rows_bytes);
+    }
+    h->p2p_ready = true;
+    return sync_descriptors(h);
+}
+
+extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
+    if (!h || !ok) return bb_fail(BB_ERR_INVALID, "null argument");
+    *ok = 0;
+    if (!h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
+    const int W = h->o.world_size;
+    ++h->p2p_seq;
+#ifdef BB_EMU
+    // single address space: the "transport" is a pointer; check that every rank's inbox is distinct and writable
+    for (int r = 0; r < W; ++r) {
+        if (!h->S.xout_rdy[r]) return BB_OK;
+        for (int q = 0; q < r; ++q) if (h->S.xout_rdy[q] == h->S.xout_rdy[r]) return BB_OK;
+    }
+    *ok = 1;
+    return BB_OK;
+#else
+    // Every rank's token carries the same sequence number only if all ranks call this the same number of times
+    // (they do: the caller votes on the outcome), so a peer's token is predictable: replace the low byte.
+    unsigned* res = nullptr;
+    BB_HIP(hipMalloc((void**)&res, 64 * 4));
+    BB_HIP(hipMemsetAsync(res, 0, 64 * 4, h->stream));
+    hipLaunchKernelGGL(k_p2p_probe_seq, dim3(1), dim3(64), 0, h->stream, h->S, h->o.rank, W, p2p_probe_words_off(h), h->p2p_seq, res);
+    int rc = launch_check();
+    unsigned host[64] = {0};
+    if (!rc) rc = d2h(host, res, sizeof host, h->stream);
+    (void)hipFree(res);
+    if (rc) return rc;
+    int good = 1;
+    for (int r = 0; r < W; ++r) good &= host[r] == 1u;
+    *ok = good;
+    return BB_OK;
+#endif
+}
+
+extern "C" int bb_p2p_enable(bb_handle* h, int32_t on) {
+    if (!h) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (on && !h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
+    h->p2p_on = on != 0;
+    const int saved_mode = h->o.launch_mode;
+    if (h->p2p_on) h->o.launch_mode = 2;      // ask setup_persistent to say why not
+    int rc = setup_persistent(h);
+    h->o.launch_mode = saved_mode;
+    if (rc || (h->p2p_on && h->persist_P == 0)) {
+        h->p2p_on = false;
+        (void)setup_persistent(h);
+        return rc ? rc : bb_fail(BB_ERR_UNSUPPORTED, "resident launch not possible on this shard");
+    }
+    return BB_OK;
 }
 
 extern "C" int64_t bb_hier_units(const bb_handle* h) {

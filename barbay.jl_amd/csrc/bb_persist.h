@@ -186,8 +186,10 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             st.h[k] = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
             if (q.s.kind >= SK_GS) {       // replicated global latents (tile 0 only): they ride along in the tile's
                 double* dst = lds + L.wk + M.K + (q.s.kind == SK_GLS ? M.nt1 : 0);   // row, every other tile adds +0.0
-                if (q.a0) dst[q.i0 - q.s.lo] = z0;
-                if (q.a1) dst[q.i0 + 1 - q.s.lo] = z1;
+                if (A.count_globals) {     // (sharded run: every rank's tile 0 holds the replicated blocks, rank 0's draw is THE draw)
+                    if (q.a0) dst[q.i0 - q.s.lo] = z0;
+                    if (q.a1) dst[q.i0 + 1 - q.s.lo] = z1;
+                }
             } else {
                 if (q.a0) lds[q.s.ldsoff + (q.i0 - q.s.lo)] = z0;
                 if (q.a1) lds[q.s.ldsoff + (q.i0 + 1 - q.s.lo)] = z1;
@@ -280,6 +282,54 @@ BB_DEV void bb_set_word(unsigned* word, unsigned v) {
 #endif
 }
 
+// ---- cross-GPU leg (XG launches): a group leader stores its group row into EVERY rank's inbox (its own included)
+// with system-scope write-through stores over xGMI, drains, then sets the row's ready word there; every tile then
+// waits for the 8 x world rows of its own rank's inbox -- local memory -- and adds them in (rank, group) order, so all
+// ranks form bit-identical totals.  Inbox words carry the ABSOLUTE step number + 1: they only ever grow, need no
+// zeroing between launches (a peer may already be writing while this rank is still launching) and a slot's parity
+// double buffer is safe for the same reason as within one GPU (nobody can publish step s + 2 before everybody has
+// consumed step s).  Inboxes live in fine-grained memory, so neither side's L2 keeps a stale line.
+BB_DEV void bb_st_sys(double* p, double v) {
+#ifdef BB_EMU
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+BB_DEV double bb_ld_sys(const double* p) {
+#ifdef BB_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+BB_DEV void bb_set_word_sys(unsigned* word, unsigned v) {
+#ifdef BB_EMU
+    *word = v;
+#else
+    __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+BB_DEV bool bb_wait_word_sys(const unsigned* word, unsigned epoch, unsigned* tmo) {
+#ifdef BB_EMU
+    (void)tmo;
+    return *word == epoch;
+#else
+    for (unsigned spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 22)) {
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+#endif
+}
+// slot of (parity, source rank, group) in an inbox
+BB_DEV long long bbx_slot(const RunArgs& A, int par, int src, int g) { return ((long long)par * A.world + src) * 8 + g; }
+
 // this tile's row (complete in lds[L.wk .. + K + 2 nt1)) -> S.prow[b], then its ready word
 BB_DEV void bbp_publish_row(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, unsigned epoch) {
     const int KK = M.K + 2 * M.nt1;
@@ -292,8 +342,9 @@ BB_DEV void bbp_publish_row(BBCtx& cx, const DevModel& M, const DevState& S, con
 }
 
 // leader of group g = tile g: wait for its members' rows, sum them in member order, publish the group row
+template <bool XG = false>
 BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par,
-                              unsigned epoch, int* ok) {
+                              unsigned epoch, int* ok, unsigned abs_epoch = 0u) {
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk), g = cx.block;
     const int members = (A.nblk - g + NG - 1) / NG;
     BB_PASS(cx, tid) {
@@ -314,19 +365,62 @@ BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, c
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s += v[i];
             }
-            bb_st<true>(S.xrow + ((long long)par * NG + g) * KK + k, s);
+            if (XG) {
+                for (int r = 0; r < A.world; ++r) bb_st_sys(S.xout[r] + bbx_slot(A, par, A.rank, g) * KK + k, s);
+            } else {
+                bb_st<true>(S.xrow + ((long long)par * NG + g) * KK + k, s);
+            }
         }
     }
     bb_drain_and_meet(cx);
-    BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * (A.nblk + par * NG + g), epoch); }
+    BB_PASS(cx, tid) {
+        if (XG) { if (tid < A.world) bb_set_word_sys(S.xout_rdy[tid] + 32 * bbx_slot(A, par, A.rank, g), abs_epoch); }
+        else if (tid == 0) bb_set_word(S.rdy + 32 * (A.nblk + par * NG + g), epoch);
+    }
     BB_STAMP(cx, S, 18);
 }
 
 // every tile: wait for the NG group rows, add them in group order -> totals in lds[L.wk], global samples in lds[L.zgl]
+template <bool XG = false>
 BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par,
-                        unsigned epoch, int* ok) {
+                        unsigned epoch, int* ok, unsigned abs_epoch = 0u) {
     double* lds = cx.lds;
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk);
+    if (XG) {
+        // the 8 x world rows of this rank's own inbox (slot order = (source rank, group) = summation order)
+        const int rows = 8 * A.world;
+        const double* in = S.xout[A.rank] + (long long)par * rows * KK;
+        const unsigned* in_rdy = S.xout_rdy[A.rank] + 32ll * par * rows;
+        BB_PASS(cx, tid) {
+            for (int j = tid; j < rows; j += cx.nthr)
+                if (!bb_wait_word_sys(in_rdy + 32 * j, abs_epoch, S.gbar + 1)) *ok = 0;
+        }
+        BB_SYNC(cx);
+        BB_STAMP(cx, S, 1);
+        // all threads fetch (row, entry) items into the moment pass's LDS scratch, whole rows per chunk; entry k's
+        // running sum lives in L.red[k] across chunks
+        double* stage = lds + L.acc;
+        double* sums = lds + L.red;
+        const int cap = (BB_NQ + 1) * cx.nthr, RC = cap / KK < rows ? cap / KK : rows;
+        for (int r0 = 0; r0 < rows; r0 += RC) {
+            const int nr = rows - r0 < RC ? rows - r0 : RC;
+            BB_PASS(cx, tid) {
+                for (int i = tid; i < nr * KK; i += cx.nthr) stage[i] = bb_ld_sys(in + (long long)r0 * KK + i);
+            }
+            BB_SYNC(cx);
+            BB_PASS(cx, tid) {
+                for (int k = tid; k < KK; k += cx.nthr) {
+                    double s = r0 == 0 ? 0.0 : sums[k];
+                    for (int r = 0; r < nr; ++r) s += stage[r * KK + k];
+                    if (r0 + nr < rows) sums[k] = s;
+                    else if (k < M.K) bb_put_total(M, L, lds, k, s);
+                    else lds[L.zgl + (k - M.K)] = s;
+                }
+            }
+            BB_SYNC(cx);
+        }
+        return;
+    }
     BB_PASS(cx, tid) {
         if (tid < NG && !bb_wait_word(S.rdy + 32 * (A.nblk + par * NG + tid), epoch, S.gbar + 1)) *ok = 0;
     }
@@ -437,7 +531,7 @@ BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const 
 }
 
 #ifndef BB_EMU
-template <int KIND, int P, int NT>
+template <int KIND, int P, int NT, bool XG = false>
 __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, RunArgs A, int NB,
                                                   unsigned long long step0, int nsteps) {
     const DevModel& M = *Mp;   // descriptors live in device memory: scalar loads on demand instead of ~1.5 KB of
@@ -455,12 +549,13 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
         {
             const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
             const unsigned epoch = (unsigned)(done + 1);
+            const unsigned abs_epoch = (unsigned)(step + 1);           // inbox words of the cross-GPU leg never restart
             const int par = (int)(step & 1);
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
             bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight
-            if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce(cx, M, S, A, L, par, epoch, ok_slot);
+            if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
             bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
-            bbp_consume(cx, M, S, A, L, par, epoch, ok_slot);
+            bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
             if (*ok_slot == 0) break;                                  // uniform: read after bbp_consume's barrier
         }
         bbp_update<KIND, P>(cx, M, S, A, NB, &st, step);

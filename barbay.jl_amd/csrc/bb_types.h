@@ -49,6 +49,8 @@ struct DevModel {
     const unsigned* counts;           // device, uint32, same indexing as loglambda minus blk_lo
 };
 
+#define BB_MAX_WORLD 16               // ranks of one resident multi-GPU run (one xGMI hive holds 8)
+
 struct DevState {
     double *mu, *om;                  // [D] variational parameters theta = [mu; omega]
     double *zsv, *asv, *hsv;          // [D] per-sample scratch: z, eps*sigmoid(omega) (= dz/domega), sigmoid/softplus (= dH/domega)
@@ -71,12 +73,19 @@ struct DevState {
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
     unsigned long long *stamps;       // [nblk][32] s_memtime stamps (diagnostic build -DBB_STAMPS only)
+    // cross-GPU leg of the resident launch's exchange (bb_p2p_*): every rank owns an INBOX -- group rows
+    // [2 parity][world][8 groups][K + 2 nt1] and their ready words [2][world][8] (one 128-B line each) -- in
+    // fine-grained memory that its peers map through IPC handles; xout[r] / xout_rdy[r] are rank r's inbox as
+    // seen from here (r == own rank: the local inbox itself)
+    double *xout[BB_MAX_WORLD];
+    unsigned *xout_rdy[BB_MAX_WORLD];
 };
 
 #define BB_ELBO_RING 4096
 
 struct RunArgs {
     long long b_lo, b_hi;             // barcode shard [b_lo, b_hi)
+    int rank, world;                  // of the sharded run (0, 1 otherwise)
     int nblk;                         // blocks of the barcode grid
     int par;                          // which ctr[] word holds the current step
     int sample, S;

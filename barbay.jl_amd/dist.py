@@ -2,6 +2,8 @@
 
 * `init_rccl(engine)`       -- in-library RCCL: rank 0 makes the id, it is broadcast, every rank joins;
                                `engine.run(n)` then issues one ncclAllReduce of K doubles per MC sample.
+* `setup_p2p(engine)`       -- the resident multi-GPU launch: IPC handles of the ranks' inboxes all-gathered, mapped,
+                               probed, switched on only if EVERY rank can (else the RCCL path stays); returns the verdict.
 * `run_external(engine, n)` -- the same step with the reduction done by `torch.distributed.all_reduce`
                                on the host buffer (any backend; this is what the gloo tests drive).
 * `gather_posterior(...)`   -- full (mean, sigma) on every rank from the per-rank shards.
@@ -20,6 +22,53 @@ def init_rccl(engine) -> None:
     ids = [engine.make_comm_id() if dist.get_rank() == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     engine.comm_init(ids[0])
+
+
+def setup_p2p(engine) -> bool:
+    """bb_p2p_export / import / selftest / enable with the two votes in between (include/barbay_hip.h).  Any backend:
+    only Python objects travel.  True: every rank's `engine.run` now is ONE resident launch per call, exchanging over
+    peer-mapped memory (xGMI between GPUs); False: nothing changed."""
+    import torch.distributed as dist
+    from ._capi import BarBayHipError
+    world = dist.get_world_size()
+
+    def vote(ok: bool) -> bool:
+        votes = [None] * world
+        dist.all_gather_object(votes, bool(ok))
+        return all(votes)
+
+    try:
+        handle = engine.p2p_export()
+    except BarBayHipError:
+        handle = None
+    handles = [None] * world
+    dist.all_gather_object(handles, handle)
+    if any(h is None for h in handles):
+        return False
+    ok = True
+    try:
+        engine.p2p_import(handles)
+    except BarBayHipError:
+        ok = False
+    if not vote(ok):
+        return False
+    try:
+        ok = engine.p2p_selftest()
+    except BarBayHipError:
+        ok = False
+    if not vote(ok):
+        return False
+    try:
+        ok = engine.p2p_enable(True)
+    except BarBayHipError:
+        ok = False
+    if not vote(ok):
+        try:
+            engine.p2p_enable(False)
+        except BarBayHipError:
+            pass
+        return False
+    return True
 
 
 def run_external(engine, n_steps: int) -> None:

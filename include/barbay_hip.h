@@ -174,6 +174,26 @@ int bb_get_posterior(bb_handle* h, double* mean, double* sigma);
 int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps,
                  int32_t n_samples, double* elbo, double* grad_mu, double* grad_omega);
 
+/* ---- cross-GPU leg of the resident launch (sharded runs, one process per GPU) ----------------------
+ * Without it a sharded run steps with two kernels + one ncclAllReduce per MC sample (bb_comm_init).
+ * With it the whole step loop of every rank is ONE launch: group leaders push their moment rows into
+ * every rank's INBOX over xGMI (peer-mapped fine-grained memory) and every rank adds the same rows in
+ * the same order.  Protocol, on every rank, same order:
+ *   bb_p2p_export(h, handle)            this rank's inbox as an IPC handle (BB_P2P_HANDLE_BYTES)
+ *   (caller all-gathers the handles, rank-major)
+ *   bb_p2p_import(h, handles)           maps the peers' inboxes
+ *   bb_p2p_selftest(h, &ok)             tokens through every mapped inbox, bounded wait
+ *   (caller ANDs `ok` over the ranks)
+ *   bb_p2p_enable(h, all_ok)            non-zero: bb_run uses the resident launch from now on;
+ *                                       BB_ERR_UNSUPPORTED if this shard cannot (caller ANDs again and
+ *                                       calls bb_p2p_enable(h, 0) everywhere if any rank refused)
+ * All ranks must then call bb_run with the same step counts.  No reference counterpart. */
+#define BB_P2P_HANDLE_BYTES 64
+int bb_p2p_export(bb_handle* h, void* handle_out);
+int bb_p2p_import(bb_handle* h, const void* handles);
+int bb_p2p_selftest(bb_handle* h, int32_t* ok);
+int bb_p2p_enable(bb_handle* h, int32_t on);
+
 /* log p(data, z) of the model (normalisers included) and its gradient at a point z
  * of the flat latent vector -- the `logdensity_and_gradient` service an HMC / NUTS
  * sampler needs (the reference's MCMC entry, src/mcmc.jl:86-160, samples the same

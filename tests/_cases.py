@@ -264,3 +264,40 @@ def case_logdensity(lib, name):
             assert np.abs(gr - gr2).max() <= 1e-9 * np.abs(gr2).max()
         mu1, om1 = e.get_params()
         assert (mu0 == mu1).all() and (om0 == om1).all()      # the variational state is untouched
+
+
+def case_p2p_resident(lib, name, world, steps=7):
+    """Sharded resident launch (bb_p2p_*): `world` handles of one process, stepped in lock step by the emulation's
+    bb_emu_run_group, against the unsharded run -- rows cross ranks through the inboxes exactly as on xGMI."""
+    import ctypes as C
+    from barbay_jl_amd import sharding
+    sp = synth(name, seed=4)
+    kw = dict(seed=5, window=4, resum_every=1)
+    with make_engine(sp, lib, launch_mode=1, **kw) as e1:
+        e1.run(steps)
+        m1, o1 = e1.get_params()
+    es = [make_engine(sp, lib, rank=r, world_size=world, **kw) for r in range(world)]
+    try:
+        handles = [e.p2p_export() for e in es]
+        for e in es:
+            e.p2p_import(handles)
+        assert all(e.p2p_selftest() for e in es)
+        assert all(e.p2p_enable(True) for e in es)
+        arr = (C.c_void_p * world)(*[e._h for e in es])
+        lib.bb_emu_run_group.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        for n in (3, steps - 3):                                   # two "launches": inbox words keep counting
+            assert lib.bb_emu_run_group(arr, world, n) == 0, lib.bb_last_error()
+        per, st = zip(*[(e.get_params(), e.stats()) for e in es])
+        lay = {n: (lo, hi) for n, lo, hi in es[0].layout()}
+        for i, ref in ((0, m1), (1, o1)):
+            full = sharding.gather_params([p[i] for p in per], st, sp.kind, lay, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env)
+            assert np.abs(full - ref).max() < 1e-10
+        # the replicated global blocks agree bit for bit on every rank
+        glo = lay["s_pop"][0], lay["logsigma_pop"][1]
+        for p in per[1:]:
+            assert (p[0][glo[0]:glo[1]] == per[0][0][glo[0]:glo[1]]).all() and (p[1][glo[0]:glo[1]] == per[0][1][glo[0]:glo[1]]).all()
+        assert all(s["persistent_pairs"] == 1 for s in st)
+        assert all(e.p2p_enable(False) for e in es)
+    finally:
+        for e in es:
+            e.close()

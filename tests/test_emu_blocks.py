@@ -97,3 +97,11 @@ def test_hier_fitness(emu_lib, name):
 @pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
 def test_logdensity_grad(emu_lib, name):
     c.case_logdensity(emu_lib, name)
+
+
+@pytest.mark.parametrize("name,world", [("fitness_multi_tile", 2), ("fitness_multi_tile", 3), ("multienv", 2), ("replicate_ragged", 2),
+                                        ("multienv_replicate", 2)])
+def test_sharded_resident_launch(emu_lib, monkeypatch, name, world):
+    monkeypatch.setenv("BB_TUNE_NB", "16")         # >= 8 tiles on every rank, one pair per thread
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    c.case_p2p_resident(emu_lib, name, world)
