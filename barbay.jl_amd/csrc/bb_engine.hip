@@ -212,6 +212,7 @@ struct bb_handle {
     void* p2p_peer[BB_MAX_WORLD] = {};       // peers' inboxes as mapped here
     bool p2p_ready = false, p2p_on = false;
     unsigned p2p_seq = 0;                    // probe sequence number (tokens only ever grow)
+    unsigned p2p_epoch0 = 0;                 // base of the inbox words: grows whenever the step counter restarts
     double* bak_mu = nullptr;          // bb_elbo_grad: saved parameters
     double* bak_om = nullptr;
     double* eps_buf = nullptr;         // device copy of caller-supplied draws
@@ -445,7 +446,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64)}; };
     const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
     const unsigned long long step = (unsigned long long)(h->step + it);
-    const unsigned epoch = (unsigned)(it + 1), abs_epoch = (unsigned)(step + 1);
+    const unsigned epoch = (unsigned)(it + 1), abs_epoch = A.xepoch0 + (unsigned)(step + 1);
     const int par = (int)(step & 1);
     const bool xg = h->p2p_on;
     if (phase == 0) {
@@ -892,6 +893,7 @@ static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, 
     A.b_hi = h->b_hi;
     A.rank = h->o.rank;
     A.world = h->o.world_size;
+    A.xepoch0 = h->p2p_epoch0;
     A.nblk = h->nblk;
     A.par = (int)(step & 1);
     A.sample = sample;
@@ -1057,6 +1059,7 @@ static int reset_optimizer(bb_handle* h) {
     }
     std::vector<double> nanv(BB_ELBO_RING, NAN);
     if ((rc = h2d(h->S.elbo_ring, nanv.data(), nanv.size() * 8, h->stream))) return rc;
+    h->p2p_epoch0 += (unsigned)h->step + 1u;   // inbox words of the cross-GPU leg never repeat, also across restarts (same on every rank)
     return set_step(h, 0);
 }
 

@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
         {
             const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
             const unsigned epoch = (unsigned)(done + 1);
-            const unsigned abs_epoch = (unsigned)(step + 1);           // inbox words of the cross-GPU leg never restart
+            const unsigned abs_epoch = A.xepoch0 + (unsigned)(step + 1);   // inbox words of the cross-GPU leg never restart
             const int par = (int)(step & 1);
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
             bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight

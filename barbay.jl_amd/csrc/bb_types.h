@@ -86,6 +86,7 @@ struct DevState {
 struct RunArgs {
     long long b_lo, b_hi;             // barcode shard [b_lo, b_hi)
     int rank, world;                  // of the sharded run (0, 1 otherwise)
+    unsigned xepoch0;                 // base of the cross-GPU inbox words (bb_persist.h)
     int nblk;                         // blocks of the barcode grid
     int par;                          // which ctr[] word holds the current step
     int sample, S;

@@ -37,6 +37,7 @@ def cpu_baseline(wl, seconds_budget: float = 20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-p2p", action="store_true", help="N > 1: keep the two-kernel + ncclAllReduce step")
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--barcodes", type=int, default=50_000)
@@ -69,6 +70,10 @@ def main():
         ids = [eng.make_comm_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init(ids[0])
+        # the resident multi-GPU launch (inboxes mapped over xGMI), only if every rank can; else the RCCL step stays
+        exchange = "p2p" if (not args.no_p2p and bb.dist.setup_p2p(eng)) else "rccl"
+    else:
+        exchange = "none"
 
     def fence():
         torch.cuda.synchronize()
@@ -76,7 +81,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.run(args.warmup)
+    if exchange == "p2p":
+        # first resident launches under a vote: a rank that times out must not leave the others behind on another path
+        ok = True
+        try:
+            eng.run(args.warmup)
+        except bb.BarBayHipError as err:
+            ok = False
+            print(f"[rank {rank}] resident multi-GPU launch failed, falling back to the RCCL step: {err}", file=sys.stderr, flush=True)
+        votes = [None] * world
+        dist.all_gather_object(votes, ok)
+        if not all(votes):
+            eng.p2p_enable(False)
+            eng.init_meanfield()                  # ranks may have stopped at different steps: start over, identically
+            exchange = "rccl (p2p fell back)"
+            eng.run(args.warmup)
+    else:
+        eng.run(args.warmup)
     fence()
     t0 = time.perf_counter()
     eng.run(args.steps)          # returns after the engine's stream has drained
@@ -146,7 +167,9 @@ def main():
             "config": {"workload": wl.name, "model": "fitness_normal", "barcodes": wl.B, "timepoints": args.timepoints,
                        "n_latents": int(st["n_latents"]), "samples_per_step": 1,
                        "optimizer": "TruncatedADAGrad(0.1, 40, 100)", "sharding": f"barcodes/{world}",
-                       "collective": "none" if world == 1 else f"1 ncclAllReduce of {int(st['n_moments'])} f64 per step"},
+                       "collective": "none" if world == 1 else (
+                           f"resident launch per rank; {int(st['n_moments'])}+ f64 rows pushed into every rank's inbox over xGMI per step"
+                           if exchange == "p2p" else f"1 ncclAllReduce of {int(st['n_moments'])} f64 per step ({exchange})")},
             "posterior_finite": finite,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -273,9 +273,12 @@ def case_p2p_resident(lib, name, world, steps=7):
     from barbay_jl_amd import sharding
     sp = synth(name, seed=4)
     kw = dict(seed=5, window=4, resum_every=1)
+    refs = []
     with make_engine(sp, lib, launch_mode=1, **kw) as e1:
-        e1.run(steps)
-        m1, o1 = e1.get_params()
+        for _ in range(2):                                             # second pass: restarted from the initial state
+            e1.init_meanfield()
+            e1.run(steps)
+            refs.append(e1.get_params())
     es = [make_engine(sp, lib, rank=r, world_size=world, **kw) for r in range(world)]
     try:
         handles = [e.p2p_export() for e in es]
@@ -285,13 +288,16 @@ def case_p2p_resident(lib, name, world, steps=7):
         assert all(e.p2p_enable(True) for e in es)
         arr = (C.c_void_p * world)(*[e._h for e in es])
         lib.bb_emu_run_group.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
-        for n in (3, steps - 3):                                   # two "launches": inbox words keep counting
-            assert lib.bb_emu_run_group(arr, world, n) == 0, lib.bb_last_error()
-        per, st = zip(*[(e.get_params(), e.stats()) for e in es])
         lay = {n: (lo, hi) for n, lo, hi in es[0].layout()}
-        for i, ref in ((0, m1), (1, o1)):
-            full = sharding.gather_params([p[i] for p in per], st, sp.kind, lay, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env)
-            assert np.abs(full - ref).max() < 1e-10
+        for m1, o1 in refs:                                            # the restart must not meet the first pass's inbox words
+            for e in es:
+                e.init_meanfield()
+            for n in (3, steps - 3):                                   # two "launches": inbox words keep counting
+                assert lib.bb_emu_run_group(arr, world, n) == 0, lib.bb_last_error()
+            per, st = zip(*[(e.get_params(), e.stats()) for e in es])
+            for i, ref in ((0, m1), (1, o1)):
+                full = sharding.gather_params([p[i] for p in per], st, sp.kind, lay, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env)
+                assert np.abs(full - ref).max() < 1e-10
         # the replicated global blocks agree bit for bit on every rank
         glo = lay["s_pop"][0], lay["logsigma_pop"][1]
         for p in per[1:]:

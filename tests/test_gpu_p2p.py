@@ -34,8 +34,10 @@ def _worker(rank, world, port, case, steps, out_dir):
     e = make_engine(sp, None, seed=5, window=4, resum_every=1, rank=rank, world_size=world, device=0)
     on = bb.dist.setup_p2p(e)
     st0 = e.stats()
-    e.run(3)
-    e.run(steps - 3)
+    for _ in range(2):            # the second pass restarts from the initial state with the inboxes still holding the first's words
+        e.init_meanfield()
+        e.run(3)
+        e.run(steps - 3)
     mean, sigma = bb.dist.gather_posterior(e, sp.kind, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env)
     st = e.stats()
     if rank == 0:
