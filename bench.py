@@ -110,6 +110,15 @@ def main():
     st = eng.stats()
     mu, sigma = eng.posterior()
     finite = bool(np.isfinite(mu).all() and np.isfinite(sigma).all())
+    replicas_equal = None
+    if world > 1:
+        # every rank updates its copy of the global latents from the totals it assembled: any lost or stale moment row
+        # on any rank shows up as a difference between the copies
+        lay = {n: (lo, hi) for n, lo, hi in eng.layout()}
+        glo, ghi = lay["s_pop"][0], lay["logsigma_pop"][1]
+        copies = [None] * world
+        dist.all_gather_object(copies, (mu[glo:ghi].tobytes(), sigma[glo:ghi].tobytes()))
+        replicas_equal = all(c == copies[0] for c in copies)
 
     roofline = None
     if world == 1 and st["persistent_pairs"] > 0:
@@ -171,6 +180,7 @@ def main():
                            f"resident launch per rank; {int(st['n_moments'])}+ f64 rows pushed into every rank's inbox over xGMI per step"
                            if exchange == "p2p" else f"1 ncclAllReduce of {int(st['n_moments'])} f64 per step ({exchange})")},
             "posterior_finite": finite,
+            "replicated_latents_identical_on_all_ranks": replicas_equal,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
