@@ -56,10 +56,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    # BB_BENCH_REHEARSAL=1 (one-GPU boxes): all ranks on device 0, gloo instead of RCCL (which refuses two ranks on one
+    # device), no in-library communicator -- the N > 1 branches of this file and the resident multi-rank launch still run
+    rehearsal = world > 1 and os.environ.get("BB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    tdev = "cpu" if rehearsal else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import barbay_jl_amd as bb
     from barbay_jl_amd import synth
@@ -67,9 +76,10 @@ def main():
     wl = synth.fitness_normal(args.barcodes, args.timepoints, seed=42)
     eng = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, device=local_rank, rank=rank, world_size=world)
     if world > 1:
-        ids = [eng.make_comm_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0])
+        if not rehearsal:
+            ids = [eng.make_comm_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            eng.comm_init(ids[0])
         # the resident multi-GPU launch (inboxes mapped over xGMI), only if every rank can; else the RCCL step stays
         exchange = "p2p" if (not args.no_p2p and bb.dist.setup_p2p(eng)) else "rccl"
     else:
@@ -104,7 +114,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()
@@ -121,7 +131,7 @@ def main():
         replicas_equal = all(c == copies[0] for c in copies)
 
     roofline = None
-    if world == 1 and st["persistent_pairs"] > 0:
+    if st["persistent_pairs"] > 0:      # (N > 1: rank 0's launch and rank 0's shard of the bytes -- a per-GPU figure)
         # resident launch: the timed region IS the kernel (HIP events on the engine's stream bracket its launches)
         launches = max(int(st["launches_last_run"]), 1)
         steps_per_launch = args.steps / launches
@@ -143,7 +153,9 @@ def main():
                     "avg_launch_us": round(sp["avg_update_ms"] * 1e3, 2),
                     "other_kernels": {"k_sample": {"avg_launch_us": round(sp["avg_sample_ms"] * 1e3, 2),
                                                    "algorithmic_bytes_per_launch": int(sp["bytes_sample"])}}}
-    if roofline is not None:
+    if roofline is not None and world > 1:
+        roofline["scope"] = "rank 0's GPU and its shard of the bytes"
+    if roofline is not None and world == 1:
         tr = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         if os.path.exists(tr):
             try:
@@ -177,7 +189,7 @@ def main():
                        "n_latents": int(st["n_latents"]), "samples_per_step": 1,
                        "optimizer": "TruncatedADAGrad(0.1, 40, 100)", "sharding": f"barcodes/{world}",
                        "collective": "none" if world == 1 else (
-                           f"resident launch per rank; {int(st['n_moments'])}+ f64 rows pushed into every rank's inbox over xGMI per step"
+                           f"resident launch per rank; 8 group rows of {int(st['n_moments'])} + 2(T-1) f64 pushed into every rank's inbox over xGMI per step"
                            if exchange == "p2p" else f"1 ncclAllReduce of {int(st['n_moments'])} f64 per step ({exchange})")},
             "posterior_finite": finite,
             "replicated_latents_identical_on_all_ranks": replicas_equal,
