@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: the sharded resident launch (bb_p2p_*) at full C2 size with W processes ON ONE GPU (gloo carries
 handles and votes; a one-GPU box has no xGMI peer).  Every rank gets 256 / W tiles so that all ranks' grids are resident
-together.  Prints steps/s and the deviation from the unsharded run.   python tools/p2p_rehearsal.py [W] [steps]"""
+together.  Prints steps/s and the deviation from the unsharded run.   python tools/p2p_rehearsal.py [W] [steps] [native]"""
 import os
 import socket
 import sys
@@ -45,8 +45,10 @@ def worker(rank, world, port, steps, out):
 if __name__ == "__main__":
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-    os.environ["BB_TUNE_NB"] = str(-(-50_000 // (256 // W * W) ) if False else -(-(50_000 // W) // (256 // W)))
-    os.environ["BB_TUNE_NTHR"] = "1024"
+    native = len(sys.argv) > 3 and sys.argv[3] == "native"      # the geometry a real W-GPU run picks per rank (small tiles, many per CU here)
+    if not native:
+        os.environ["BB_TUNE_NB"] = str(-(-(50_000 // W) // (256 // W)))
+        os.environ["BB_TUNE_NTHR"] = "1024"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -55,7 +57,8 @@ if __name__ == "__main__":
     if os.path.exists(out):
         import barbay_jl_amd as bb
         from barbay_jl_amd import synth
-        os.environ.pop("BB_TUNE_NB"); os.environ.pop("BB_TUNE_NTHR")
+        os.environ.pop("BB_TUNE_NB", None)
+        os.environ.pop("BB_TUNE_NTHR", None)
         wl = synth.fitness_normal(50_000, 8, 42)
         e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42)
         e.run(200 + steps)
