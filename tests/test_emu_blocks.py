@@ -105,3 +105,10 @@ def test_sharded_resident_launch(emu_lib, monkeypatch, name, world):
     monkeypatch.setenv("BB_TUNE_NB", "16")         # >= 8 tiles on every rank, one pair per thread
     monkeypatch.setenv("BB_TUNE_NTHR", "512")
     c.case_p2p_resident(emu_lib, name, world)
+
+
+def test_sharded_resident_launch_chunked_inbox(emu_lib, monkeypatch):
+    """64-thread tiles: the 8 x world inbox rows do not fit the LDS stage at once and are summed chunk by chunk."""
+    monkeypatch.setenv("BB_TUNE_NB", "8")
+    monkeypatch.setenv("BB_TUNE_NTHR", "64")
+    c.case_p2p_resident(emu_lib, "fitness_multi_tile", 3)
