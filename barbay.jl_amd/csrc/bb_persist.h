@@ -86,6 +86,7 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
     int* li = (int*)(lds + L.misc);
     BB_PASS(cx, tid) {
         if (tid == 0) { li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0); li[1] = 1; /* exchange ok word */ }
+        for (int k = tid; k < M.K + 2 * M.nt1; k += cx.nthr) lds[L.wk + k] = 0.0;
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
@@ -165,11 +166,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
     BB_STAMP(cx, S, 20);
-    BB_PASS(cx, tid) {
-        BBPst<P>& st = BB_PSTATE(stv, tid);
-        for (int k = tid; k < M.K + 2 * M.nt1; k += cx.nthr) lds[L.wk + k] = 0.0;
-    }
-    BB_SYNC(cx);
+    // (the tile's row lds[L.wk ..] was zeroed by the previous step's G pass / the prologue: no pass + barrier for it here)
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
@@ -336,7 +333,14 @@ BB_DEV void bbp_publish_row(BBCtx& cx, const DevModel& M, const DevState& S, con
     BB_PASS(cx, tid) {
         for (int k = tid; k < KK; k += cx.nthr) bb_st<true>(S.prow + (long long)cx.block * KK + k, cx.lds[L.wk + k]);
     }
-    bb_drain_and_meet(cx);
+    if (KK <= 64) {
+        // one wave stored the whole row: its own drain orders the ready word behind the row, no workgroup barrier
+#ifndef BB_EMU
+        if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    } else {
+        bb_drain_and_meet(cx);
+    }
     BB_STAMP(cx, S, 7);
     BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
 }
@@ -350,8 +354,8 @@ BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, c
     BB_PASS(cx, tid) {
         if (tid < members && !bb_wait_word(S.rdy + 32 * (g + tid * NG), epoch, S.gbar + 1)) *ok = 0;
     }
-    BB_SYNC(cx);
-    BB_STAMP(cx, S, 17);
+    BB_SYNC(cx);      // (kept although one wave does all of the leader's work when KK <= 64: letting the tile's other waves
+    BB_STAMP(cx, S, 17);   //  run ahead beside that wave's dependent chain cost 2 %)
     // thread k owns row entry k: its members' values come straight into registers, 16 loads in flight (more would raise the kernel's register peak), and are
     // added in member order (coalesced across k; no LDS staging, no extra barrier)
     BB_PASS(cx, tid) {
@@ -424,7 +428,15 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
     BB_PASS(cx, tid) {
         if (tid < NG && !bb_wait_word(S.rdy + 32 * (A.nblk + par * NG + tid), epoch, S.gbar + 1)) *ok = 0;
     }
-    BB_SYNC(cx);
+    if (KK <= 64) {
+        // the polling lanes and the reading lanes are one wave: it has left every poll loop before it loads (the wait
+        // also keeps the compiler from hoisting the row loads); the other waves meet it at the barrier below
+#ifndef BB_EMU
+        if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    } else {
+        BB_SYNC(cx);
+    }
     BB_STAMP(cx, S, 1);
     BB_PASS(cx, tid) {
         for (int k = tid; k < KK; k += cx.nthr) {
@@ -458,6 +470,8 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBSlot wslot = bb_slot_of(A, step);
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
+        // the totals in lds[L.wk ..] have been consumed (F pass): clear the row for the next step's partial sums
+        for (int k = tid; k < M.K + 2 * M.nt1; k += cx.nthr) lds[L.wk + k] = 0.0;
         double* hs_m = nullptr;
         double* hs_o = nullptr;
         if (A.opt == 0) {
