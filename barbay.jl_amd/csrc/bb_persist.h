@@ -87,6 +87,8 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
     BB_PASS(cx, tid) {
         if (tid == 0) { li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0); li[1] = 1; /* exchange ok word */ }
         for (int k = tid; k < M.K + 2 * M.nt1; k += cx.nthr) lds[L.wk + k] = 0.0;
+        if (KIND <= 1)      // neutral units: no own fitness, no own precision (the mutants' entries are refreshed every step)
+            for (int u = tid; u < NB * bb_xdim<KIND>(M); u += cx.nthr) { lds[L.seff + u] = 0.0; lds[L.weff + u] = 0.0; }
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
@@ -190,13 +192,29 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             } else {
                 if (q.a0) lds[q.s.ldsoff + (q.i0 - q.s.lo)] = z0;
                 if (q.a1) lds[q.s.ldsoff + (q.i0 + 1 - q.s.lo)] = z1;
+                if (KIND <= 1) {
+                    // fitness / multienv: a unit's effective fitness IS its s sample and its precision exp(-2 logsigma):
+                    // the owning thread fills the tables here, the E pass and its barrier are not needed (the neutral
+                    // units' zero entries were set once in the prologue)
+                    const int X = bb_xdim<KIND>(M);
+                    const long long u0 = (long long)t.nshift * X + (q.i0 - q.s.lo);
+                    if (q.s.kind == SK_S) {
+                        if (q.a0) lds[L.seff + u0] = z0;
+                        if (q.a1) lds[L.seff + u0 + 1] = z1;
+                    } else if (q.s.kind == SK_LS_E) {
+                        if (q.a0) lds[L.weff + u0] = bb_exp(-2.0 * z0);
+                        if (q.a1) lds[L.weff + u0 + 1] = bb_exp(-2.0 * z1);
+                    }
+                }
             }
         }
     }
     BB_SYNC(cx);
     BB_STAMP(cx, S, 21);
-    BB_PASS(cx, tid) { bb_effective_tables<KIND>(cx, tid, M, S, L, t, false); }
-    BB_SYNC(cx);
+    if (KIND > 1) {
+        BB_PASS(cx, tid) { bb_effective_tables<KIND>(cx, tid, M, S, L, t, false); }
+        BB_SYNC(cx);
+    }
     BB_STAMP(cx, S, 22);
     bb_pass_moments<KIND, true>(cx, M, S, L, t, NB, false);
     BB_STAMP(cx, S, 23);
