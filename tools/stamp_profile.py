@@ -13,7 +13,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 out = os.path.join(g.PKG, "lib", "libbarbay_hip_stamps.so")
-if "--build-only" in sys.argv or not os.path.exists(out):
+stale = not os.path.exists(out) or any(os.path.getmtime(os.path.join(os.path.dirname(g.SRC), f)) > os.path.getmtime(out)
+                                        for f in os.listdir(os.path.dirname(g.SRC)))
+if "--build-only" in sys.argv or stale:
     subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-DBB_STAMPS", "-fPIC", "-shared",
                     "-Wl,-Bsymbolic", g.SRC, "-o", out, "-ldl"], check=True)
     if "--build-only" in sys.argv:
