@@ -475,6 +475,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
             bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
             if (xg) bbp_consume<true>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
             else bbp_consume<false>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
+            bbp_finish<KIND>(cx, h->M, h->S, A, h->NB);
             bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
         }
     } else {

@@ -468,10 +468,20 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
             else lds[L.zgl + (k - M.K)] = s;
         }
     }
-    BB_SYNC(cx);
+    // the F pass that follows (bbp_finish) reads these totals with threads j < Ttot: when they and the summing threads
+    // k < KK are all wave 0, that wave's own program order is enough; F ends with the barrier everybody needs
+    if (!(KK <= 64 && M.Ttot <= 64)) BB_SYNC(cx);
 }
 
-// ---- second half: totals, global finish, residuals, per-latent gradient, optimiser in registers ----------
+// ---- F pass: everything that depends only on the totals (ends with a workgroup barrier) -----------------------
+template <int KIND>
+BB_DEV void bbp_finish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
+    BB_STAMP(cx, S, 25);
+    bb_finalize_finish<KIND>(cx, M, S, A, L);
+}
+
+// ---- second half: residuals, per-latent gradient, optimiser in registers ----------
 template <int KIND, int P>
 BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                        unsigned long long step) {
@@ -480,8 +490,6 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
-    BB_STAMP(cx, S, 25);
-    bb_finalize_finish<KIND>(cx, M, S, A, L);
     BB_STAMP(cx, S, 26);
     bb_pass_residuals_units<KIND>(cx, M, S, L, t, NB);
     BB_STAMP(cx, S, 27);
@@ -588,7 +596,8 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
             if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
             bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
             bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
-            if (*ok_slot == 0) break;                                  // uniform: read after bbp_consume's barrier
+            bbp_finish<KIND>(cx, M, S, A, NB);
+            if (*ok_slot == 0) break;                                  // uniform: read after the F pass's barrier
         }
         bbp_update<KIND, P>(cx, M, S, A, NB, &st, step);
     }
