@@ -775,8 +775,9 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         const size_t lds_cap = (size_t)160 * 1024 / (size_t)bpc;
         int nthr = 0;
         for (;;) {
-            const int per_mutant = M.kind == 0 ? 2 : (M.kind == 1 ? 2 * M.E : (M.kind == 2 ? 3 : (M.kind == 3 ? 1 + 3 * M.R : M.E * (1 + 3 * M.R))));
-            const long long pairs = (long long)NB * (M.Ttot + per_mutant) / 2;   // one pair of latents per thread is the sweet spot
+            // one pair of latents per thread is the sweet spot; counted with the segments' rounding (tile_pairs_bound), the
+            // number the resident launch sizes its per-thread state by (a tile of 257 pairs on 256 threads would need two)
+            const long long pairs = tile_pairs_bound(M, NB);
             // > 1 pair per thread: 512 threads (256-VGPR budget, up to 4 pairs) beat 1024 threads with spills (C3: 28.8k vs 18.8k steps/s)
             // (768 threads x 2 pairs was tried for C3: 138 spills at 168 VGPRs, 23.0k vs 28.8k steps/s for 512 x 3)
             nthr = pairs > 2048 ? 1024 : (pairs > 1024 ? 512 : (pairs > 512 ? 1024 : (pairs > 256 ? 512 : 256)));

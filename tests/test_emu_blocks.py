@@ -112,3 +112,24 @@ def test_sharded_resident_launch_chunked_inbox(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NB", "8")
     monkeypatch.setenv("BB_TUNE_NTHR", "64")
     c.case_p2p_resident(emu_lib, "fitness_multi_tile", 3)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c2_shards_are_eligible_for_the_resident_launch(emu_lib, world):
+    """The headline workload split over 2 / 4 / 8 ranks: every rank's geometry must leave one pair per thread and >= 8 tiles,
+    otherwise bench.py --gpus N silently stays on the RCCL step (W = 4 used to: 257 pairs on 256 threads)."""
+    from barbay_jl_amd import synth
+    import barbay_jl_amd as bb
+    wl = synth.fitness_normal(50_000, 8, 42)
+    es = [bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, rank=r, world_size=world, _lib=emu_lib) for r in range(world)]
+    try:
+        handles = [e.p2p_export() for e in es]
+        for e in es:
+            e.p2p_import(handles)
+        assert all(e.p2p_selftest() for e in es)
+        assert all(e.p2p_enable(True) for e in es)
+        st = [e.stats() for e in es]
+        assert all(s["persistent_pairs"] == 1 and s["n_blocks"] >= 8 for s in st), st
+    finally:
+        for e in es:
+            e.close()
