@@ -597,7 +597,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     bb_handle* h = new bb_handle();
     h->o = *opts;
     { const char* fr = getenv("BB_FORCE_ALLREDUCE"); h->force_reduce = fr && atoi(fr) > 0; }
-    if (h->o.resum_every <= 0) h->o.resum_every = h->o.window > 0 ? h->o.window : 1;
+    if (h->o.resum_every < 0) h->o.resum_every = 0;      // 0 = the default schedule (bb_slot_of)
     DevModel& M = h->M;
     M.kind = md->kind;
     M.R = md->n_rep;

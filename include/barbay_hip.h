@@ -97,7 +97,9 @@ typedef struct bb_advi_opts {
     int32_t window;           /* TruncatedADAGrad n, default 100                         */
     int32_t resum_every;      /* TruncatedADAGrad: 1 = re-add the whole window every step
                                  (same arithmetic as the reference's sum(g2)); k > 1 =
-                                 running sum, exact re-add every k steps; 0 = window     */
+                                 running sum, exact re-add every k steps; 0 (default) =
+                                 at every multiple of `window` up to 10 windows, then at
+                                 every multiple of 10 windows                            */
     double pre;               /* DecayedADAGrad, default 1.0                             */
     double post;              /* DecayedADAGrad, default 0.9                             */
     uint64_t seed;            /* Philox key (DESIGN.md "RNG stream")                     */

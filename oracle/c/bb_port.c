@@ -230,7 +230,7 @@ void port_normals(uint64_t seed, uint32_t step, uint32_t stream, int64_t D, doub
 
 /* AdvancedVI.optimize!: n_steps of grad(-ELBO) -> optimiser -> theta -= delta, theta = [mu; omega] in place.
  * opt 0: TruncatedADAGrad(eta, tau, window): window_exact != 0 re-adds the whole window every step (the
- *        reference's `sum(g2)`), else a running sum re-added exactly once per window.
+ *        reference's `sum(g2)`), else a running sum re-added exactly once per window for ten windows, then once per ten.
  * opt 1: DecayedADAGrad(eta, pre, post).
  * state: caller-allocated, zero-initialised: opt 0 -> (window + 1) * 2D doubles, opt 1 -> 2D doubles set to 1e-8. */
 int port_run(const port_model* M, double* mu, double* omega, int64_t first_step, int64_t n_steps, int S, int opt,
@@ -250,7 +250,8 @@ int port_run(const port_model* M, double* mu, double* omega, int64_t first_step,
         const double el = port_elbo_grad(M, mu, omega, eps, S, gmu, gom, work, nthreads);
         if (elbo_trace) elbo_trace[it - first_step] = el;
         const int slot = (int)(it % window);
-        const int resum = window_exact || (it > 0 && it % window == 0);
+        /* default schedule of the engine (bb_slot_of): once per window during the first ten windows, then once per ten */
+        const int resum = window_exact || (it > 0 && it % window == 0 && (it <= 10 * (int64_t)window || it % (10 * (int64_t)window) == 0));
 #pragma omp parallel for schedule(static)
         for (int64_t j = 0; j < 2 * D; ++j) {
             double* p = j < D ? &mu[j] : &omega[j - D];

@@ -133,3 +133,18 @@ def test_c2_shards_are_eligible_for_the_resident_launch(emu_lib, world):
     finally:
         for e in es:
             e.close()
+
+
+def test_default_readd_schedule_tracks_the_exact_window(emu_lib):
+    """TruncatedADAGrad's running window under the default re-add schedule (once per window for ten windows, then once per
+    ten) against the reference's arithmetic (the whole window re-added every step, resum_every = 1) over 2 200 steps: the
+    running sum's cancellation error must stay at rounding level (a fixed re-add every 1 000 steps leaves 6e-6)."""
+    from conftest import make_engine
+    sp = c.synth("fitness_multi_tile", seed=4)
+    out = []
+    for k in (1, 0):
+        with make_engine(sp, emu_lib, seed=5, resum_every=k) as e:
+            e.run(2200)
+            out.append(e.posterior())
+    assert np.abs(out[1][0] - out[0][0]).max() < 1e-9
+    assert np.abs(out[1][1] / out[0][1] - 1).max() < 1e-9
