@@ -139,6 +139,7 @@ def test_default_readd_schedule_tracks_the_exact_window(emu_lib):
     """TruncatedADAGrad's running window under the default re-add schedule (once per window for ten windows, then once per
     ten) against the reference's arithmetic (the whole window re-added every step, resum_every = 1) over 2 200 steps: the
     running sum's cancellation error must stay at rounding level (a fixed re-add every 1 000 steps leaves 6e-6)."""
+    import numpy as np
     from conftest import make_engine
     sp = c.synth("fitness_multi_tile", seed=4)
     out = []
