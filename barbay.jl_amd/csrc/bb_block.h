@@ -143,7 +143,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.zs3 = o;  o += NB * (kind == 4 ? E : 1);
     L.seff = o; o += NB * X;
     L.weff = o; o += NB * X;
-    L.res = o;  o += 0;   // (residuals are formed inline: bb_residual)
+    L.res = 0;            // (set below: the a_tb table of the resident launch)
     L.As = o;   o += NB * X;
     L.Qs = o;   o += NB * X;
     L.acc = o;  o += (BB_NQ + 1) * nthr;
@@ -162,6 +162,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.seg = o;  o += 5 * (BB_MAX_SEG + 1);
     L.zgl = o;  o += 2 * nt1;
     L.lam = o;  o += with_lam ? NB * Ttot : 0;   // exp(loglambda sample) of the tile (resident launch only)
+    L.res = o;  o += with_lam ? NB * Ttot : 0;   // a_tb = (l[t+1] - l[t]) - s_eff, filled in the exchange's shadow (resident launch only)
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -805,9 +806,12 @@ BB_DEV void bb_finalize(BBCtx& cx, const DevModel& M, const DevState& S, const R
 
 // Residual r = (l[t+1] - l[t]) - s_eff - c_t of (barcode bl, time step tt) of replicate r, formed from the staged
 // samples where it is needed (no residual table, no separate pass).
-template <int KIND>
+// TABLE (resident launch): the part that does not depend on the totals, a = (l[t+1] - l[t]) - s_eff, was left in
+// lds[L.res + NB tcum[r] + bl T + tt] while the moment rows were in flight (bbp_residual_ahead).
+template <int KIND, bool TABLE = false>
 BB_DEV double bb_residual(const double* lds, const DevModel& M, const BBLds& L, const BBTile& t, int NB, int X, int r, int bl, int tt) {
     const int T = M.T[r], tc = M.tcum[r];
+    if (TABLE && !(KIND == 3 && M.quirk)) return lds[L.res + NB * tc + bl * T + tt] - lds[L.cc + tc + tt];
     const double* zl = lds + L.zl + NB * tc + bl * T + tt;
     double a = zl[1] - zl[0];
     if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof<KIND>(M, r, tt)];
@@ -817,7 +821,7 @@ BB_DEV double bb_residual(const double* lds, const DevModel& M, const BBLds& L, 
 }
 
 // pass U: the per-unit sums As = sum_t w r (= dlogp/ds_eff) and Qs = sum_t (w r^2 - 1) (= dlogp/dlogsigma_eff).
-template <int KIND>
+template <int KIND, bool TABLE = false>
 BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState& S, const BBLds& L, const BBTile& t, int NB) {
     double* lds = cx.lds;
     const int X = bb_xdim<KIND>(M);
@@ -835,7 +839,7 @@ BB_DEV void bb_pass_residuals_units(BBCtx& cx, const DevModel& M, const DevState
                 for (int tt = 0; tt < T1; ++tt) {
                     if (KIND == 1 && M.env_idx[tt + 1] != x) continue;
                     if (KIND == 4 && M.env_idx[M.tcum[r] + tt + 1] != x - r * M.E) continue;
-                    const double rr = bb_residual<KIND>(lds, M, L, t, NB, X, r, bl, tt);
+                    const double rr = bb_residual<KIND, TABLE>(lds, M, L, t, NB, X, r, bl, tt);
                     as += w * rr;
                     qs += w * rr * rr - 1.0;
                 }
@@ -870,12 +874,12 @@ BB_DEV double bb_glik(const double* lds, const DevModel& M, const BBLds& L, cons
         if (tt < T1) {
             const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt)]
                                  : lds[L.wbar + tc + (qk ? bb_qj(M, T1, tt, t.b0 + bl) : tt)];
-            g += w * bb_residual<KIND>(lds, M, L, t, NB, X, r, bl, tt);
+            g += w * bb_residual<KIND, LAM_IN_LDS>(lds, M, L, t, NB, X, r, bl, tt);
         }
         if (tt > 0) {
             const double w = mut ? lds[L.weff + bl * X + bb_xof<KIND>(M, r, tt - 1)]
                                  : lds[L.wbar + tc + (qk ? bb_qj(M, T1, tt - 1, t.b0 + bl) : tt - 1)];
-            g -= w * bb_residual<KIND>(lds, M, L, t, NB, X, r, bl, tt - 1);
+            g -= w * bb_residual<KIND, LAM_IN_LDS>(lds, M, L, t, NB, X, r, bl, tt - 1);
         }
         return g;
     }

@@ -473,6 +473,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
         for (int b = 0; b < h->nblk; ++b) {
             BBCtx cx = cxof(b);
             bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
+            bbp_residual_ahead<KIND>(cx, h->M, h->NB, A);
             if (xg) bbp_consume<true>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
             else bbp_consume<false>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
             bbp_finish<KIND>(cx, h->M, h->S, A, h->NB);

@@ -158,6 +158,33 @@ BB_DEV void bbp_draw_ahead(BBCtx& cx, const DevModel& M, const RunArgs& A, int N
     }
 }
 
+// ---- the totals-independent part of every residual, a_tb = (l[t+1] - l[t]) - s_eff, tabulated while the rows fly -------
+// (b, t) lanes as in the moment pass; read after the exchange by the R/U and G passes (two LDS reads per residual
+// instead of four).  The ragged replicate method's neutral term depends on the sampled global latents, which only
+// come back with the totals: that one case keeps forming its residuals inline.
+template <int KIND>
+BB_DEV void bbp_residual_ahead(BBCtx& cx, const DevModel& M, int NB, const RunArgs& A) {
+    if (KIND == 3 && M.quirk) return;
+    const BBLds L = bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
+    const BBTile t = bb_tile(M, A, cx.block, NB);
+    double* lds = cx.lds;
+    const int X = bb_xdim<KIND>(M);
+    for (int r = 0; r < M.R; ++r) {
+        const int T = M.T[r], tc = M.tcum[r];
+        const double* zl = lds + L.zl + NB * tc;
+        BB_PASS(cx, tid) {
+            for (int i = tid; i < t.nbt * T; i += cx.nthr) {
+                const int bl = (int)bb_umulhi((unsigned)i, M.Tmagic[r]), tt = i - bl * T;
+                if (tt < T - 1) {
+                    double a = zl[i + 1] - zl[i];
+                    if (bl >= t.nshift) a -= lds[L.seff + bl * X + bb_xof<KIND>(M, r, tt)];
+                    lds[L.res + NB * tc + i] = a;
+                }
+            }
+        }
+    }
+}
+
 // ---- first half of a step: draw, stage, moments, publish the tile's K partial rows ---------------------
 template <int KIND, int P>
 BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
@@ -491,7 +518,7 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
     BB_STAMP(cx, S, 26);
-    bb_pass_residuals_units<KIND>(cx, M, S, L, t, NB);
+    bb_pass_residuals_units<KIND, true>(cx, M, S, L, t, NB);
     BB_STAMP(cx, S, 27);
     const BBSlot wslot = bb_slot_of(A, step);
     BB_PASS(cx, tid) {
@@ -595,6 +622,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
             bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight
             if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
             bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
+            bbp_residual_ahead<KIND>(cx, M, NB, A);                    // ... and the totals-independent half of the residuals is tabulated
             bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
             bbp_finish<KIND>(cx, M, S, A, NB);
             if (*ok_slot == 0) break;                                  // uniform: read after the F pass's barrier
