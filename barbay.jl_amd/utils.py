@@ -9,6 +9,7 @@ Python harness exposes the same `vi.advi(data=...)` surface and its tests read l
 from __future__ import annotations
 
 from dataclasses import dataclass
+from itertools import chain
 from typing import Any, List, Optional, Sequence, Union
 
 import numpy as np
@@ -172,14 +173,14 @@ def advi_to_df(data: pd.DataFrame, dist, vars: Sequence[str], *, id_col="barcode
         rep = np.empty(len(df), dtype=object)
         for (lo, hi), g in zip(var_range, var_groups):
             if "̲ₜ" in g:
-                rep[lo:hi] = "R1" if n_rep == 1 else sum([[f"R{r + 1}"] * (_ntime(output, r) - 1) for r in range(n_rep)], [])
+                rep[lo:hi] = "R1" if n_rep == 1 else list(chain.from_iterable([f"R{r + 1}"] * (_ntime(output, r) - 1) for r in range(n_rep)))
             elif g == "θ̲⁽ᵐ⁾":
                 rep[lo:hi] = "N/A"
             elif g == "logΛ̲̲":
-                rep[lo:hi] = "R1" if n_rep == 1 else sum(
-                    [[f"R{r + 1}"] * ((n_bc + n_neutral) * _ntime(output, r)) for r in range(n_rep)], [])
+                rep[lo:hi] = "R1" if n_rep == 1 else list(chain.from_iterable(
+                    [f"R{r + 1}"] * ((n_bc + n_neutral) * _ntime(output, r)) for r in range(n_rep)))
             else:
-                rep[lo:hi] = "R1" if n_rep == 1 else sum([[f"R{r + 1}"] * (n_bc * n_env) for r in range(n_rep)], [])
+                rep[lo:hi] = "R1" if n_rep == 1 else list(chain.from_iterable([f"R{r + 1}"] * (n_bc * n_env) for r in range(n_rep)))
         df[rep_col] = rep
     if env_col is not None:                                                        # add_environment_info! :1164-1187
         env = np.empty(len(df), dtype=object)
@@ -190,7 +191,7 @@ def advi_to_df(data: pd.DataFrame, dist, vars: Sequence[str], *, id_col="barcode
                 # the reference assigns `output.envs[2:end]` (:1179), which only fits one replicate; with replicates
                 # the block holds (T_r - 1) entries per replicate, so the per-replicate lists are concatenated
                 per = output.envs if (output.envs and isinstance(output.envs[0], (list, tuple))) else [output.envs] * max(n_rep, 1)
-                env[lo:hi] = sum([list(e[1:]) for e in per], [])
+                env[lo:hi] = list(chain.from_iterable(e[1:] for e in per))
             elif g != "logΛ̲̲":
                 # the reference fills θ̲⁽ᵐ⁾ only and leaves the other blocks #undef (:1182-1184); the
                 # per-environment blocks are stored env-fastest (model_multienv_fitness_normal.jl:271-272)
@@ -203,16 +204,16 @@ def advi_to_df(data: pd.DataFrame, dist, vars: Sequence[str], *, id_col="barcode
         if "̲ₜ" in g:
             ids[lo:hi] = "N/A"
         elif g == "θ̲⁽ᵐ⁾" and genotype_col is None:
-            ids[lo:hi] = output.bc_ids if n_env == 1 else sum([[b] * n_env for b in output.bc_ids], [])
+            ids[lo:hi] = output.bc_ids if n_env == 1 else list(chain.from_iterable([b] * n_env for b in output.bc_ids))
         elif g == "θ̲⁽ᵐ⁾":
             ids[lo:hi] = list(dict.fromkeys(output.genotypes))
         elif g == "logΛ̲̲":
             all_ids = list(output.neutral_ids) + list(output.bc_ids)
-            ids[lo:hi] = sum([[b] * _ntime(output, r) for r in range(n_rep) for b in all_ids], [])
+            ids[lo:hi] = list(chain.from_iterable([b] * _ntime(output, r) for r in range(n_rep) for b in all_ids))
         elif n_env == 1:
             ids[lo:hi] = list(output.bc_ids) * n_rep
         else:
-            ids[lo:hi] = sum([[b] * n_env for _ in range(n_rep) for b in output.bc_ids], [])
+            ids[lo:hi] = list(chain.from_iterable([b] * n_env for _ in range(n_rep) for b in output.bc_ids))
     df["id"] = ids
     if len(var_groups) == 7 and (n_rep > 1 or genotype_col is not None):          # :1457-1459
         df = _process_hierarchical_samples(df, output, n_samples, rep_col, env_col, genotype_col, rng,
