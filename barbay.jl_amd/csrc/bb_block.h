@@ -23,14 +23,14 @@
 
 #ifdef BB_EMU
 #define BB_DEV static inline
-struct BBCtx { int nthr; int block; double* lds; };
+struct BBCtx { int nthr; int block; double* lds; const void* lay = nullptr; /* resident launch: its BBLds, precomputed */ };
 #define BB_PASS(cx, tid) for (int tid = 0; tid < (cx).nthr; ++tid)
 #define BB_SYNC(cx) ((void)0)
 BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 #else
 #include <hip/hip_runtime.h>
 #define BB_DEV __device__ __forceinline__
-struct BBCtx { int nthr; int block; double* lds; };
+struct BBCtx { int nthr; int block; double* lds; const void* lay = nullptr; /* resident launch: its BBLds, precomputed */ };
 #define BB_PASS(cx, tid) for (int tid = threadIdx.x, _once = 1; _once; _once = 0)
 #define BB_SYNC(cx) __syncthreads()
 BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }

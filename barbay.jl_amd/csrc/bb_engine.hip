@@ -233,6 +233,8 @@ struct bb_handle {
     int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
     DevModel* dM = nullptr;            // device copies of the descriptors for the persistent launch
     DevState* dS = nullptr;
+    BBLds* dL = nullptr;               // ... and of the resident launch's LDS carve-up (host copy: Lp)
+    BBLds Lp{};
     bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
     bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
 };
@@ -327,7 +329,7 @@ static int launch_check();
 // persistent launch (bb_persist.h)
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_EMU
-typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, RunArgs, int, unsigned long long, int);
+typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, unsigned long long, int);
 static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false) {
     if (xg) {                  // sharded tiles are small: one pair per thread only
         if (P != 1) return nullptr;
@@ -376,9 +378,10 @@ static long long tile_pairs_bound(const DevModel& M, long long NB) {
 // device copies of the descriptors (kernels read them through pointers); re-sent whenever the host copy changes
 static int sync_descriptors(bb_handle* h) {
     int rc;
-    if (!h->dM && ((rc = dalloc(h, &h->dM, 1)) || (rc = dalloc(h, &h->dS, 1)))) return rc;
+    if (!h->dM && ((rc = dalloc(h, &h->dM, 1)) || (rc = dalloc(h, &h->dS, 1)) || (rc = dalloc(h, &h->dL, 1)))) return rc;
     if ((rc = h2d(h->dM, &h->M, sizeof(DevModel), h->stream)) || (rc = h2d(h->dS, &h->S, sizeof(DevState), h->stream))) return rc;
-    return 0;
+    h->Lp = bb_lds_layout(h->M.R, h->M.E, h->M.kind, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);   // the resident launch's carve-up
+    return h2d(h->dL, &h->Lp, sizeof(BBLds), h->stream);
 }
 
 static int setup_persistent(bb_handle* h) {
@@ -443,7 +446,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     bb_handle* h = E.h;
     const RunArgs& A = E.A;
     BBPst<PP>* st = (BBPst<PP>*)E.st.data();
-    auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64)}; };
+    auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), &h->Lp}; };
     const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
     const unsigned long long step = (unsigned long long)(h->step + it);
     const unsigned epoch = (unsigned)(it + 1), abs_epoch = A.xepoch0 + (unsigned)(step + 1);
@@ -554,7 +557,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
         BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
         BB_HIP(hipMemsetAsync(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4, h->stream));
         A = make_args(h, h->step, 0, 1, true, false);
-        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, A, h->NB,
+        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB,
                            (unsigned long long)h->step, n);
         rc = launch_check();
         h->step += n;
