@@ -1,0 +1,40 @@
+"""The block programs' host emulation under AddressSanitizer (GPU ASan is not available on the pool): LDS carve-up, per-thread
+LDS slots, exchange rows and the multi-rank inboxes are all plain host memory there, so an index that strays is caught."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "barbay.jl_amd", "csrc", "bb_engine.hip")
+OUT = os.path.join(ROOT, "tests", "_emu", "libbb_emu_asan.so")
+
+SCRIPT = r'''
+import ctypes, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from barbay_jl_amd import _capi
+import _cases as c
+lib = _capi._declare(ctypes.CDLL(%(lib)r))
+os.environ["BB_TUNE_NB"] = "16"; os.environ["BB_TUNE_NTHR"] = "512"
+c.case_p2p_resident(lib, "fitness_multi_tile", 3, steps=5)
+c.case_p2p_resident(lib, "multienv_replicate", 2, steps=5)
+del os.environ["BB_TUNE_NB"]; del os.environ["BB_TUNE_NTHR"]
+c.case_persistent_equals_two_kernel(lib, "replicate_ragged")
+c.case_hier_fitness(lib, "genotype")
+print("ASAN-CLEAN")
+'''
+
+
+def test_emulated_engine_under_asan():
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not found")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    deps = [os.path.join(os.path.dirname(SRC), f) for f in os.listdir(os.path.dirname(SRC))]
+    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-DBB_EMU", "-fPIC",
+                        "-shared", "-Wl,-Bsymbolic", "-x", "c++", SRC, "-o", OUT], check=True)
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "lib": OUT}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ASAN-CLEAN" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
