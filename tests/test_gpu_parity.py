@@ -183,3 +183,20 @@ def test_hier_fitness(hip_lib, name):
 @pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
 def test_logdensity_grad(hip_lib, name):
     c.case_logdensity(hip_lib, name)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_runs_are_bit_reproducible(hip_lib, mode):
+    """Every cross-thread and cross-workgroup sum has a fixed order (no floating-point atomics anywhere): two runs of the same
+    handle settings give bit-identical parameters -- at full C2 size, where a race in the exchange or in the LDS hand-offs of
+    the resident launch (mode 2) / the two-kernel path (mode 1) would show as run-to-run noise."""
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import port
+    sp = port.spec_from_workload(synth.fitness_normal(50_000, 8, 42))
+    outs = []
+    for _ in range(2):
+        with make_engine(sp, hip_lib, seed=42, launch_mode=mode) as e:
+            e.run(250)                       # past the first window re-adds
+            outs.append(e.get_params())
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
