@@ -20,7 +20,13 @@
 
 // The resident launch's LDS carve-up is computed once on the host and read from device memory where needed: recomputing it in
 // every pass of every step (ten times ~70 scalar instructions) was a visible share of each wave's issue slots.
-BB_DEV const BBLds& bbp_layout(const BBCtx& cx) { return *(const BBLds*)cx.lay; }
+// (only where it pays: the 1024-thread instances, whose 128-VGPR / SGPR budget is the tight one; the 512-thread instances
+// measured 2 % slower with it and keep computing)
+template <int KIND>
+BB_DEV BBLds bbp_layout(const BBCtx& cx, const DevModel& M, int NB) {
+    if (cx.lay) return *(const BBLds*)cx.lay;
+    return bb_lds_layout(M.R, M.E, KIND, M.Ttot, M.nt1, M.K, NB, cx.nthr, 1);
+}
 
 template <int P>
 struct BBPst {
@@ -83,7 +89,7 @@ template <int P> BB_DEV bb_u2* bbp_cnt(BBCtx& cx, const BBLds& L) { return (bb_u
 // ---- prologue: segment table, state into registers -------------------------------------------------
 template <int KIND, int P>
 BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     BBSeg* sg = (BBSeg*)(lds + L.seg);
@@ -151,7 +157,7 @@ void bbp_draw_ahead_call(bb_d2* eps, int nthr, int tid, unsigned long long seed,
 
 template <int KIND, int P>
 BB_DEV void bbp_draw_ahead(BBCtx& cx, const DevModel& M, const RunArgs& A, int NB, BBPst<P>* stv, unsigned long long step) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     bb_d2* eps = bbp_eps(cx, L);
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
@@ -169,7 +175,7 @@ BB_DEV void bbp_draw_ahead(BBCtx& cx, const DevModel& M, const RunArgs& A, int N
 template <int KIND>
 BB_DEV void bbp_residual_ahead(BBCtx& cx, const DevModel& M, int NB, const RunArgs& A) {
     if (KIND == 3 && M.quirk) return;
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     const BBTile t = bb_tile(M, A, cx.block, NB);
     double* lds = cx.lds;
     const int X = bb_xdim<KIND>(M);
@@ -193,7 +199,7 @@ BB_DEV void bbp_residual_ahead(BBCtx& cx, const DevModel& M, int NB, const RunAr
 template <int KIND, int P>
 BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                        unsigned long long step) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
@@ -257,7 +263,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 template <int KIND, int P>
 BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                               unsigned long long step) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
@@ -507,7 +513,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
 // ---- F pass: everything that depends only on the totals (ends with a workgroup barrier) -----------------------
 template <int KIND>
 BB_DEV void bbp_finish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     BB_STAMP(cx, S, 25);
     bb_finalize_finish<KIND>(cx, M, S, A, L);
 }
@@ -516,7 +522,7 @@ BB_DEV void bbp_finish(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 template <int KIND, int P>
 BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                        unsigned long long step) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
@@ -581,7 +587,7 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 template <int KIND, int P>
 BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
                          unsigned long long step_end) {
-    const BBLds& L = bbp_layout(cx);
+    const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
@@ -608,7 +614,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
     const DevModel& M = *Mp;   // descriptors live in device memory: scalar loads on demand instead of ~1.5 KB of
     const DevState& S = *Sp;   // kernel arguments held (and spilled) in SGPRs across the whole step loop
     extern __shared__ __attribute__((aligned(16))) double bbp_smem[];
-    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bbp_smem, Lp};
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bbp_smem, NT > 512 ? (const void*)Lp : nullptr};
     BBPst<P> st;
     int* ok_slot = (int*)(bbp_smem + Lp->misc) + 1;
     bbp_prologue<KIND, P>(cx, M, S, A, NB, &st);
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
         const unsigned long long step = step0 + (unsigned long long)done;
         bbp_sample<KIND, P>(cx, M, S, A, NB, &st, step);
         {
-            const BBLds& L = bbp_layout(cx);
+            const BBLds L = bbp_layout<KIND>(cx, M, NB);
             const unsigned epoch = (unsigned)(done + 1);
             const unsigned abs_epoch = A.xepoch0 + (unsigned)(step + 1);   // inbox words of the cross-GPU leg never restart
             const int par = (int)(step & 1);
