@@ -10,6 +10,7 @@
  *                                              src/model_multienv_fitness_normal.jl:146-302
  *                                              src/model_fitness_normal_hierarchical_genotypes.jl:165-329
  *                                              src/model_fitness_normal_hierarchical_replicates.jl:158-331, 420-637
+ *                                              src/model_multienv_fitness_normal_hierarchical_replicates.jl:158-363, 449-687
  *   in the "independent Poisson" form: Poisson(n_t | sum_b lam) * Multinomial(R_t | n_t, F_t)
  *   == prod_b Poisson(R_tb | lam_tb) when n_t == sum_b R_tb (docs/src/math.md:405-407), with the gradient
  *   written out by hand (direct sums over barcodes; no moment tables);
@@ -30,11 +31,11 @@
 #define LOG2PI 1.8378770664093454835606594728112
 
 typedef struct {
-    int kind, R, E, G;              /* 0 fitness, 1 multienv, 2 genotype, 3 replicate */
+    int kind, R, E, G;              /* 0 fitness, 1 multienv, 2 genotype, 3 replicate, 4 multienv_replicate */
     int64_t nn, nb, D;
     int T[MAXR];
     const int64_t* counts;          /* replicate-major, each T_r x B column-major */
-    const int32_t* env_idx;         /* [T] */
+    const int32_t* env_idx;         /* [T]; kind 4: replicate-major [sum_r T_r] */
     const int32_t* geno_idx;        /* [nb] */
     const double* pmean;            /* [D] prior mean per latent */
     const double* pstd;             /* [D] prior std per latent */
@@ -46,20 +47,29 @@ static double softplus(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
 static double sigmoid(double x) { double e = exp(-fabs(x)); return x >= 0 ? 1.0 / (1.0 + e) : e / (1.0 + e); }
 
 /* effective fitness / log-sigma of mutant m at time step t of replicate r, and chain-rule scatter */
-static inline double s_eff(const port_model* M, const double* z, int64_t m, int r, int t) {
+/* (eo = offset of replicate r's time points in env_idx: kind 4 only, 0 otherwise) */
+static inline int64_t unit4(const port_model* M, int64_t m, int r, int t, int eo) {   /* theta_tilde / logtau / logsigma [e, m, r], e fastest */
+    return (int64_t)r * M->nb * M->E + m * M->E + M->env_idx[eo + t + 1];
+}
+static inline double s_eff(const port_model* M, const double* z, int64_t m, int r, int t, int eo) {
     switch (M->kind) {
     case 0: return z[M->o_s + m];
     case 1: return z[M->o_s + m * M->E + M->env_idx[t + 1]];
     case 2: return z[M->o_s + M->geno_idx[m]] + exp(z[M->o_lt + m]) * z[M->o_tt + m];
-    default: return z[M->o_s + m] + exp(z[M->o_lt + r * M->nb + m]) * z[M->o_tt + r * M->nb + m];
+    case 3: return z[M->o_s + m] + exp(z[M->o_lt + r * M->nb + m]) * z[M->o_tt + r * M->nb + m];
+    default: {   /* model_multienv_..._replicates.jl:241, 311: s = theta[e, m] + exp(logtau[e, m, r]) * theta_tilde[e, m, r] */
+        const int64_t u = unit4(M, m, r, t, eo);
+        return z[M->o_s + m * M->E + M->env_idx[eo + t + 1]] + exp(z[M->o_lt + u]) * z[M->o_tt + u];
+    }
     }
 }
-static inline int64_t ls_index(const port_model* M, int64_t m, int r, int t) {
+static inline int64_t ls_index(const port_model* M, int64_t m, int r, int t, int eo) {
     switch (M->kind) {
     case 0: return M->o_ls + m;
     case 1: return M->o_ls + m * M->E + M->env_idx[t + 1];
     case 2: return M->o_ls + m;
-    default: return M->o_ls + r * M->nb + m;
+    case 3: return M->o_ls + r * M->nb + m;
+    default: return M->o_ls + unit4(M, m, r, t, eo);
     }
 }
 
@@ -78,7 +88,7 @@ double port_logjoint_grad(const port_model* M, const double* z, double* g, int n
         g[i] = -d / M->pstd[i];
     }
     int64_t lo = M->o_l, co = 0;
-    int to = 0;
+    int to = 0, eo = 0;
     for (int r = 0; r < M->R; ++r) {
         const int T = M->T[r];
         const double* l = z + lo;
@@ -112,7 +122,7 @@ double port_logjoint_grad(const port_model* M, const double* z, double* g, int n
                 const double sbar = z[M->o_spop + to + t];
                 double mean, lsv;
                 if (b < M->nn) { mean = -sbar; lsv = z[M->o_lspop + to + t]; }
-                else { mean = s_eff(M, z, b - M->nn, r, t) - sbar; lsv = z[ls_index(M, b - M->nn, r, t)]; }
+                else { mean = s_eff(M, z, b - M->nn, r, t, eo) - sbar; lsv = z[ls_index(M, b - M->nn, r, t, eo)]; }
                 const double w = exp(-2.0 * lsv), res = gam - mean;
                 lnorm += -0.5 * w * res * res - lsv - 0.5 * LOG2PI;
                 const double dres = -w * res;           /* d/d res */
@@ -125,7 +135,7 @@ double port_logjoint_grad(const port_model* M, const double* z, double* g, int n
                 else {
                     const int64_t m = b - M->nn;
                     const double ds = -dres;            /* d/d s_eff */
-                    g[ls_index(M, m, r, t)] += w * res * res - 1.0;
+                    g[ls_index(M, m, r, t, eo)] += w * res * res - 1.0;
                     switch (M->kind) {
                     case 0: g[M->o_s + m] += ds; break;
                     case 1: g[M->o_s + m * M->E + M->env_idx[t + 1]] += ds; break;
@@ -136,11 +146,19 @@ double port_logjoint_grad(const port_model* M, const double* z, double* g, int n
                         /* theta[geno]: several mutants share it -> accumulated below, serially */
                         break;
                     }
-                    default: {
+                    case 3: {
                         const double et = exp(z[M->o_lt + r * M->nb + m]);
                         g[M->o_s + m] += ds;            /* one barcode per thread iteration: no race */
                         g[M->o_tt + r * M->nb + m] += ds * et;
                         g[M->o_lt + r * M->nb + m] += ds * et * z[M->o_tt + r * M->nb + m];
+                        break;
+                    }
+                    default: {
+                        const int64_t u = unit4(M, m, r, t, eo);
+                        const double et = exp(z[M->o_lt + u]);
+                        g[M->o_s + m * M->E + M->env_idx[eo + t + 1]] += ds;   /* this barcode's entries only: no race */
+                        g[M->o_tt + u] += ds * et;
+                        g[M->o_lt + u] += ds * et * z[M->o_tt + u];
                     }
                     }
                 }
@@ -152,7 +170,7 @@ double port_logjoint_grad(const port_model* M, const double* z, double* g, int n
                 for (int t = 0; t < T - 1; ++t) {
                     const int64_t b = M->nn + m;
                     const double gam = (l[b * T + t + 1] - l[b * T + t]) - (L[t + 1] - L[t]);
-                    const double res = gam - (s_eff(M, z, m, r, t) - z[M->o_spop + to + t]);
+                    const double res = gam - (s_eff(M, z, m, r, t, eo) - z[M->o_spop + to + t]);
                     g[M->o_s + M->geno_idx[m]] += exp(-2.0 * z[M->o_ls + m]) * res;
                 }
         }
@@ -171,6 +189,7 @@ double port_logjoint_grad(const port_model* M, const double* z, double* g, int n
         lo += (int64_t)T * B;
         co += (int64_t)T * B;
         to += T - 1;
+        if (M->kind == 4) eo += T;
     }
     return lp;
 }

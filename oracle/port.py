@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "c", "bb_port.c")
 LIB = os.path.join(_HERE, "c", "libbb_port.so")
 MAXR = 16
-_KIND = {"fitness": 0, "multienv": 1, "genotype": 2, "replicate": 3}
+_KIND = {"fitness": 0, "multienv": 1, "genotype": 2, "replicate": 3, "multienv_replicate": 4}
 _dp = C.POINTER(C.c_double)
 
 
@@ -72,7 +72,8 @@ class Port:
         self._counts = np.concatenate([np.ascontiguousarray(c.T).reshape(-1) for c in sp.counts]).astype(np.int64)
         m.counts = _p(self._counts, C.POINTER(C.c_int64))
         if sp.env_idx is not None:
-            self._env = np.ascontiguousarray(sp.env_idx, dtype=np.int32)
+            env = np.concatenate(sp.env_idx) if sp.kind == "multienv_replicate" else sp.env_idx    # replicate-major [sum T_r]
+            self._env = np.ascontiguousarray(env, dtype=np.int32)
             m.env_idx = _p(self._env, C.POINTER(C.c_int32))
         if sp.geno_idx is not None:
             self._geno = np.ascontiguousarray(sp.geno_idx, dtype=np.int32)

@@ -21,7 +21,7 @@ def test_port_elbo_grad_fixtures(name, nthreads):
     assert np.abs(go - go2).max() <= 1e-12 * np.abs(go).max()
 
 
-@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged"])
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "genotype", "replicate_ragged", "multienv_replicate"])
 @pytest.mark.parametrize("opt", ["TruncatedADAGrad", "DecayedADAGrad"])
 def test_port_trajectory(name, opt):
     sp = c.synth(name, seed=6)
@@ -39,3 +39,17 @@ def test_port_normals_match_numpy_stream():
     out = np.empty(1001)
     port.lib().port_normals(77, 5, 2, 1001, out.ctypes.data_as(port._dp))
     assert np.abs(out - rng.normals(77, 5, 2, 1001)).max() < 1e-13
+
+
+@pytest.mark.parametrize("name", ["multienv_replicate", "multienv_replicate_3d"])
+def test_port_elbo_grad_multienv_replicate(name):
+    """The fifth model (no reference fixture exercises it): the port against the literal transcription on synthetic data."""
+    sp = c.synth(name, seed=3)
+    p = port.Port(sp)
+    mu, om = advi.meanfield_init(3, sp.D)
+    mu, om = mu * 0.2 + 3, om * 0.5 - 2
+    eps = np.stack([rng.normals(3, 0, s, sp.D) for s in range(2)])
+    el, gm, go = literal.elbo_and_grad(mu, om, eps, sp)
+    el2, gm2, go2 = p.elbo_grad(mu, om, eps, nthreads=2)
+    assert abs(el - el2) <= 1e-12 * abs(el)
+    assert np.abs(gm - gm2).max() <= 1e-12 * np.abs(gm).max() and np.abs(go - go2).max() <= 1e-12 * np.abs(go).max()
