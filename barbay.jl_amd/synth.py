@@ -83,6 +83,28 @@ def multienv_fitness_normal(B: int = 20_000, T: int = 6, envs=(1, 1, 2, 3, 4, 1)
                     name=f"multienv_fitness_normal {B}x{T} envs {envs} seed {seed}")
 
 
+def multienv_replicate_fitness_normal(B: int = 12_000, T=(6, 5, 6), envs=((1, 1, 2, 3, 1, 2), (1, 2, 3, 1, 2), (1, 3, 2, 1, 3, 2)),
+                                      seed: int = 46) -> Workload:
+    """The fifth model (no BASELINE config of its own): per-environment hyper-fitness theta_{e,b} ~ U(-0.2, 0.8),
+    s_{e,b,r} = theta_{e,b} + N(0, 0.05); ragged replicates, each with its own environment sequence."""
+    g = np.random.default_rng(seed)
+    nn = max(1, B // 50)
+    T = list(T)
+    flat = [e for es in envs for e in es]
+    uniq = list(dict.fromkeys(flat))                       # indexin.(envs, Ref(unique(vcat(envs...))))
+    theta = g.uniform(-0.2, 0.8, (len(uniq), B - nn))
+    counts, env_idx = [], []
+    for r, Tr in enumerate(T):
+        assert len(envs[r]) == Tr
+        ei = np.asarray([uniq.index(e) for e in envs[r]], dtype=np.int32)
+        sr = theta + g.normal(0.0, 0.05, theta.shape)
+        steps = [np.concatenate([np.zeros(nn), sr[ei[t + 1]]]) for t in range(Tr - 1)]
+        counts.append(_trajectory(g, _f0(g, B), steps, 200 * B))
+        env_idx.append(ei)
+    return Workload("multienv_replicate", counts, nn, B - nn, env_idx=env_idx, truth={"theta": theta},
+                    name=f"multienv_replicate_fitness_normal {B}x{T} seed {seed}")
+
+
 def genotype_fitness_normal(B: int = 200_000, T: int = 8, G: int = 5_000, seed: int = 45) -> Workload:
     """Config C5: barcodes dealt to genotypes in contiguous blocks, s_b = theta_g + N(0, 0.05)."""
     g = np.random.default_rng(seed)

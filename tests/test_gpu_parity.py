@@ -137,7 +137,7 @@ def test_persistent_full_size_matches_two_kernel(hip_lib):
     assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-9 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-9
 
 
-@pytest.mark.parametrize("cfg", ["C3_replicate", "C4_multienv", "C5_genotype"])
+@pytest.mark.parametrize("cfg", ["C3_replicate", "C4_multienv", "C5_genotype", "multienv_replicate"])
 def test_full_size_other_configs(hip_lib, cfg):
     """BASELINE configs 3-5 at full size: the engine's ELBO gradient on a fixed draw equals the oracle's C port,
     60 optimiser steps stay finite and raise the ELBO, and (where eligible) the resident launch equals the
@@ -147,7 +147,8 @@ def test_full_size_other_configs(hip_lib, cfg):
     from oracle import port, rng
     wl = {"C3_replicate": lambda: synth.replicate_fitness_normal(20_000, 6, 3, 43),
           "C4_multienv": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
-          "C5_genotype": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45)}[cfg]()
+          "C5_genotype": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45),
+          "multienv_replicate": lambda: synth.multienv_replicate_fitness_normal()}[cfg]()
     sp = port.spec_from_workload(wl)
     p = port.Port(sp)
     with make_engine(sp, hip_lib, seed=7, elbo_every=20, launch_mode=1) as e:

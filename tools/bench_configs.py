@@ -17,6 +17,7 @@ CFG = {
     "C3 replicate_fitness_normal 20000x6x3": lambda: synth.replicate_fitness_normal(20_000, 6, 3, 43),
     "C4 multienv_fitness_normal 20000x6 E=4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
     "C5 genotype_fitness_normal 200000x8 G=5000": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45),
+    "(no BASELINE config) multienv_replicate_fitness_normal 12000x(6,5,6) E=3": lambda: synth.multienv_replicate_fitness_normal(),
 }
 steps = int(os.environ.get("STEPS", 2000))
 for name, mk in CFG.items():
