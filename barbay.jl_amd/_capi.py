@@ -20,6 +20,7 @@ BB_OPT_DECAYED_ADAGRAD = 1
 BB_COMM_ID_BYTES = 128
 BB_P2P_HANDLE_BYTES = 64
 BB_ERR_UNSUPPORTED = -4
+BB_ERR_NONFINITE = -5
 
 EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
@@ -73,6 +74,10 @@ class bb_stats(C.Structure):
 
 class BarBayHipError(RuntimeError):
     """Raised for any non-zero status of the C ABI (the reference throws ErrorException)."""
+
+
+class BarBayNonFinite(BarBayHipError):
+    """bb_run took its steps but the variational parameters went NaN / Inf (BB_ERR_NONFINITE); the state can still be read."""
 
 
 def _declare(lib: C.CDLL) -> C.CDLL:
@@ -216,6 +221,8 @@ class Engine:
 
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, rc: int):
+        if rc == BB_ERR_NONFINITE:
+            raise BarBayNonFinite(f"barbay_hip error {rc}: {self._lib.bb_last_error().decode()}")
         if rc != 0:
             raise BarBayHipError(f"barbay_hip error {rc}: {self._lib.bb_last_error().decode()}")
 

@@ -72,6 +72,9 @@ template <bool COH> BB_DEV void bb_st(double* p, double v) {
 #endif
     *p = v;
 }
+#ifndef BB_GUARD
+#define BB_GUARD 0x1p24    /* running-window cancellation guard of bb_opt_apply: re-add an element exactly beyond this ratio */
+#endif
 #define BB_MAX_SEG (4 + 4 * BB_MAX_REP)
 
 // ------------------------------------------------------------------------------------------------
@@ -341,12 +344,14 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
     if (A.opt == 0) {   // TruncatedADAGrad: g2[mod(i-1,n)+1] = d^2; s = sum(g2); d *= eta / (tau + sqrt(s))
         const double n2 = d * d;
         *new_slot = n2;
-        double s;
-        if (w.resum) {
+        // running sum acc + d^2 - (slot leaving the window); where that difference has cancelled more than 24 bits (a gradient
+        // spike leaving the window: t >> s, or a negative rounding residue) this ELEMENT's window is re-added exactly on the
+        // spot, whatever the schedule says -- rare, and it bounds the running sum's relative error by 2^-29 between re-adds
+        const double t = *acc + n2;
+        double s = t - old_slot;
+        if (w.resum || t > BB_GUARD * s) {
             s = 0.0;
             for (int j = 0; j < A.W; ++j) s += (j == w.slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
-        } else {
-            s = fmax(*acc + n2 - old_slot, 0.0);
         }
         *acc = s;
         upd = d * (A.eta * bb_rcp(A.tau + bb_sqrt(s)));
@@ -975,7 +980,13 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
                     *slot = (A.first_sample ? 0.0 : *slot) + v / (double)A.S;
                 }
             }
-            if (A.last_sample && A.apply) S.ctr[1 - A.par] = step + 1;
+            if (A.last_sample && A.apply) {
+                S.ctr[1 - A.par] = step + 1;
+                // divergence flag: a NaN / Inf anywhere in theta reaches the exchanged moment totals
+                double chk = 0.0;
+                for (int k = 0; k < M.K - 2; ++k) chk += lds[L.wk + k];
+                if (!(chk - chk == 0.0)) S.hstatus[1] = 1u;
+            }
         }
     }
     BB_SYNC(cx);

@@ -191,6 +191,21 @@ static int rccl_load() {
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
+// Every entry point that takes a handle runs with the handle's device current and restores the caller's on exit: the
+// caller may have switched devices since bb_create (torch.cuda.set_device, other handles on other GPUs in this process).
+#ifdef BB_EMU
+struct DevGuard { explicit DevGuard(int) {} };
+#else
+struct DevGuard {
+    int prev = -1, dev;
+    explicit DevGuard(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+    ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+#endif
+#define BB_ENTER(h) DevGuard bb_dev_guard_((h)->o.device)
+
 struct bb_handle {
     DevModel M{};
     DevState S{};
@@ -212,7 +227,10 @@ struct bb_handle {
     void* p2p_peer[BB_MAX_WORLD] = {};       // peers' inboxes as mapped here
     bool p2p_ready = false, p2p_on = false;
     unsigned p2p_seq = 0;                    // probe sequence number (tokens only ever grow)
-    unsigned p2p_epoch0 = 0;                 // base of the inbox words: grows whenever the step counter restarts
+    unsigned epoch0 = 0;                     // base of the ready / inbox words: grows whenever the step counter restarts
+    long long req_steps = 0;                 // steps ASKED of the resident launch since the last restart (equal on all ranks, whatever a timeout left undone)
+    bool p2p_first = false;                  // the next resident launch is the first since the cross-GPU leg was switched on (longer poll limit)
+    unsigned* hstatus = nullptr;             // host-mapped status words (DevState.hstatus is their device address)
     double* bak_mu = nullptr;          // bb_elbo_grad: saved parameters
     double* bak_om = nullptr;
     double* eps_buf = nullptr;         // device copy of caller-supplied draws
@@ -329,7 +347,7 @@ static int launch_check();
 // persistent launch (bb_persist.h)
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_EMU
-typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, unsigned long long, int);
+typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, int);
 static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false) {
     if (xg) {                  // sharded tiles are small: one pair per thread only
         if (P != 1) return nullptr;
@@ -449,7 +467,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), &h->Lp}; };
     const BBLds L = bb_lds_layout(h->M.R, h->M.E, KIND, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);
     const unsigned long long step = (unsigned long long)(h->step + it);
-    const unsigned epoch = (unsigned)(it + 1), abs_epoch = A.xepoch0 + (unsigned)(step + 1);
+    const unsigned abs_epoch = A.xepoch0 + (unsigned)(step + 1), epoch = abs_epoch;
     const int par = (int)(step & 1);
     const bool xg = h->p2p_on;
     if (phase == 0) {
@@ -458,7 +476,6 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
             bbp_prologue<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr);
             bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st + (size_t)b * h->nthr, (unsigned long long)h->step);
         }
-        memset(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4);
     } else if (phase == 1) {
         for (int b = 0; b < h->nblk; ++b) {
             BBCtx cx = cxof(b);
@@ -485,7 +502,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     } else {
         for (int b = 0; b < h->nblk; ++b) {
             BBCtx cx = cxof(b);
-            bbp_epilogue<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, (unsigned long long)(h->step + nsteps));
+            bbp_epilogue<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
     }
 }
@@ -539,6 +556,7 @@ extern "C" int bb_emu_run_group(bb_handle** hs, int32_t n, int64_t nsteps) {
     if (!hs || n < 1 || nsteps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
     for (int i = 0; i < n; ++i)
         if (!hs[i] || hs[i]->persist_P == 0) return bb_fail(BB_ERR_INVALID, "handle %d has no resident launch", i);
+    for (int i = 0; i < n; ++i) hs[i]->req_steps += nsteps;
     return emu_run_group(hs, n, nsteps);
 }
 #endif
@@ -546,39 +564,50 @@ extern "C" int bb_emu_run_group(bb_handle** hs, int32_t n, int64_t nsteps) {
 static int launch_persistent(bb_handle* h, long long nsteps) {
     RunArgs A = make_args(h, h->step, 0, 1, true, false);
     int rc = 0;
+    h->req_steps += nsteps;
 #ifdef BB_EMU
     (void)A;
     if (h->p2p_on) return bb_fail(BB_ERR_UNSUPPORTED, "emulation: step the ranks of a sharded resident run with bb_emu_run_group");
     rc = emu_run_group(&h, 1, nsteps);
 #else
+    // No per-launch memsets: ready words carry base + step + 1 and only grow; the timeout word is sticky (a launch that finds it
+    // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
+    // first step from the device counter.
     bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
-    while (nsteps > 0 && !rc) {
+    if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
+    do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
-        BB_HIP(hipMemsetAsync(h->S.gbar, 0, 32 * 10 * 4, h->stream));
-        BB_HIP(hipMemsetAsync(h->S.rdy, 0, (size_t)32 * (h->nblk + 16) * 4, h->stream));
-        A = make_args(h, h->step, 0, 1, true, false);
-        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB,
-                           (unsigned long long)h->step, n);
+        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB, n);
         rc = launch_check();
         h->step += n;
         nsteps -= n;
-    }
+        A.spin_limit = 1u << 23;
+    } while (nsteps > 0 && !rc);
 #endif
     return rc;
 }
 
+// after the stream has drained: the launches' status words (host-mapped, no copy)
 static int check_persistent(bb_handle* h) {
+    if (!h->hstatus) return 0;
+    volatile unsigned* st = h->hstatus;
+    if (st[0] != 0) {
+        st[0] = 0;
+        int rc = 0;
 #ifndef BB_EMU
-    unsigned g[4] = {0, 0, 0, 0};
-    int rc = d2h(g, h->S.gbar, sizeof g, h->stream);   // g[1] = timeout word
-    if (rc) return rc;
-    if (g[1] != 0) {
         unsigned long long c[2];
         if (!d2h(c, h->S.ctr, sizeof c, h->stream)) h->step = (long long)c[0];
-        return bb_fail(BB_ERR_DEVICE, "grid barrier of the persistent launch timed out (not all %d workgroups resident: device shared or masked?); "
-                                      "%lld steps completed; set launch_mode = 1", h->nblk, h->step);
-    }
+        rc = dzero(h->S.gbar, 32 * 10 * 4, h->stream);         // acknowledge: later launches may run again
+        if (!rc) rc = dsync(h->stream);
 #endif
+        (void)rc;
+        return bb_fail(BB_ERR_DEVICE, "an exchange of the resident launch timed out (not all %d workgroups resident -- device shared or masked? -- or a peer "
+                                      "rank stalled); %lld steps completed; set launch_mode = 1 or re-initialise", h->nblk, h->step);
+    }
+    if (st[1] != 0) {
+        st[1] = 0;
+        return bb_fail(BB_ERR_NONFINITE, "the variational parameters went non-finite (NaN / Inf) during the run; %lld steps done", h->step);
+    }
     return 0;
 }
 
@@ -620,9 +649,12 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
 
 #ifndef BB_EMU
     {
-        hipError_t e = hipSetDevice(opts->device);
-        if (e != hipSuccess) { delete h; return bb_fail(BB_ERR_DEVICE, "hipSetDevice(%d): %s", opts->device, hipGetErrorString(e)); }
-        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || opts->device < 0 || opts->device >= ndev) { delete h; return bb_fail(BB_ERR_DEVICE, "device %d: no such HIP device (%d visible)", opts->device, ndev); }
+    }
+    BB_ENTER(h);
+    {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete h; return bb_fail(BB_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
@@ -830,6 +862,23 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
     BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
     BB_TRY(dalloc(h, &S.gbar, (size_t)32 * 10));
+#ifdef BB_EMU
+    h->hstatus = (unsigned*)calloc(16, sizeof(unsigned));
+    S.hstatus = h->hstatus;
+#else
+    {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 16 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            bb_destroy(h);
+            return bb_fail(BB_ERR_DEVICE, "cannot allocate the host-mapped status words");
+        }
+        memset(hp, 0, 16 * sizeof(unsigned));
+        h->hstatus = (unsigned*)hp;
+        S.hstatus = (unsigned*)dp;
+    }
+#endif
     BB_TRY(dalloc(h, &S.prow, (size_t)h->nblk * (M.K + 2 * M.nt1)));
     BB_TRY(dalloc(h, &S.xrow, (size_t)2 * 8 * (M.K + 2 * M.nt1)));
     BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 16)));
@@ -863,6 +912,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
 static void p2p_release(bb_handle* h);
 extern "C" void bb_destroy(bb_handle* h) {
     if (!h) return;
+    BB_ENTER(h);
 #ifndef BB_EMU
     (void)hipStreamSynchronize(h->stream);
     if (h->graph) (void)hipGraphExecDestroy(h->graph);
@@ -871,6 +921,11 @@ extern "C" void bb_destroy(bb_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
 #endif
     p2p_release(h);
+#ifdef BB_EMU
+    free(h->hstatus);
+#else
+    if (h->hstatus) (void)hipHostFree(h->hstatus);
+#endif
     for (void* p : h->owned) dfree(p);
     if (h->eps_buf) dfree(h->eps_buf);
     if (h->dbg_buf) dfree(h->dbg_buf);
@@ -899,7 +954,8 @@ static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, 
     A.b_hi = h->b_hi;
     A.rank = h->o.rank;
     A.world = h->o.world_size;
-    A.xepoch0 = h->p2p_epoch0;
+    A.xepoch0 = h->epoch0;
+    A.spin_limit = 1u << 23;                  // ~1 us per poll: seconds, not milliseconds
     A.nblk = h->nblk;
     A.par = (int)(step & 1);
     A.sample = sample;
@@ -1065,12 +1121,16 @@ static int reset_optimizer(bb_handle* h) {
     }
     std::vector<double> nanv(BB_ELBO_RING, NAN);
     if ((rc = h2d(h->S.elbo_ring, nanv.data(), nanv.size() * 8, h->stream))) return rc;
-    h->p2p_epoch0 += (unsigned)h->step + 1u;   // inbox words of the cross-GPU leg never repeat, also across restarts (same on every rank)
+    // ready / inbox words never repeat, also across restarts: the base moves by the steps ASKED of the resident launch since
+    // the last restart -- the same number on every rank of a sharded run, wherever a timeout may have stopped each of them
+    h->epoch0 += (unsigned)h->req_steps + 1u;
+    h->req_steps = 0;
     return set_step(h, 0);
 }
 
 extern "C" int bb_init_meanfield(bb_handle* h) {
     if (!h) return bb_fail(BB_ERR_INVALID, "null handle");
+    BB_ENTER(h);
     const int nb = (int)std::min<long long>(((h->M.D + 1) / 2 + 255) / 256, 1024);
 #ifdef BB_EMU
     emu_launch(nb, 256, 0, [&](BBCtx& cx) { bb_block_init(cx, h->M, h->S, h->o.seed, nb); });
@@ -1084,6 +1144,7 @@ extern "C" int bb_init_meanfield(bb_handle* h) {
 
 extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega) {
     if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     int rc;
     if ((rc = h2d(h->S.mu, mu, (size_t)h->M.D * 8, h->stream))) return rc;
     if ((rc = h2d(h->S.om, omega, (size_t)h->M.D * 8, h->stream))) return rc;
@@ -1092,6 +1153,7 @@ extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega
 
 extern "C" int bb_get_params(bb_handle* h, double* mu, double* omega) {
     if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     int rc;
     if ((rc = dsync(h->stream))) return rc;
     if ((rc = d2h(mu, h->S.mu, (size_t)h->M.D * 8, h->stream))) return rc;
@@ -1100,6 +1162,7 @@ extern "C" int bb_get_params(bb_handle* h, double* mu, double* omega) {
 
 extern "C" int bb_get_posterior(bb_handle* h, double* mean, double* sigma) {
     if (!h || !mean || !sigma) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     int rc = bb_get_params(h, mean, sigma);
     if (rc) return rc;
     for (long long i = 0; i < h->M.D; ++i) {   // sigma = softplus(omega), O(D) once at the end
@@ -1134,9 +1197,11 @@ static int build_graph(bb_handle* h, int steps) {
 
 extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_ENTER(h);
     if (h->sample != 0) return bb_fail(BB_ERR_INVALID, "a split-phase step is in flight");
     int rc = 0;
     int64_t done = 0;
+    if (h->hstatus) h->hstatus[1] = 0;          // divergence flag of THIS run (nothing of this handle is in flight here)
 #ifndef BB_EMU
     BB_HIP(hipEventRecord(h->ev0, h->stream));
 #endif
@@ -1180,12 +1245,13 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     BB_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_run_ms = ms;
 #endif
-    if (h->persist_P > 0 && (rc = check_persistent(h))) return rc;
+    if ((rc = check_persistent(h))) return rc;
     return BB_OK;
 }
 
 extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
     if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_ENTER(h);
 #ifdef BB_EMU
     return bb_run(h, n_steps);
 #else
@@ -1225,6 +1291,7 @@ extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
 extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps, int32_t S,
                             double* elbo, double* grad_mu, double* grad_omega) {
     if (!h || !mu || !omega || S < 1) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_ENTER(h);
     if (h->o.world_size > 1 && !eps) return bb_fail(BB_ERR_UNSUPPORTED, "bb_elbo_grad on a sharded handle needs explicit eps");
     const size_t D = (size_t)h->M.D;
     int rc;
@@ -1285,6 +1352,7 @@ extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega,
 // sampler asks of a model (`LogDensityProblems.logdensity_and_gradient`; the reference's src/mcmc.jl:86-160 path)
 extern "C" int bb_logdensity_grad(bb_handle* h, const double* z, double* logp, double* grad) {
     if (!h || !z) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     const size_t D = (size_t)h->M.D;
     const double om1 = 0.54132485461291810;                  // log(e - 1): softplus = 1
     if (h->ld_omega.size() != D) { h->ld_omega.assign(D, om1); h->ld_zero.assign(D, 0.0); }
@@ -1297,6 +1365,7 @@ extern "C" int bb_logdensity_grad(bb_handle* h, const double* z, double* logp, d
 
 extern "C" int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out) {
     if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_ENTER(h);
     if (h->o.elbo_every <= 0) return bb_fail(BB_ERR_INVALID, "ELBO recording is off (elbo_every = 0)");
     std::vector<double> ring(BB_ELBO_RING);
     int rc = dsync(h->stream);
@@ -1315,6 +1384,7 @@ extern "C" int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, do
 
 extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, int64_t hi, double* out) {
     if (!h || !out || lo < 0 || hi < lo) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_ENTER(h);
     const size_t n = (size_t)(hi - lo);
     if (n == 0) return BB_OK;
     int rc;
@@ -1339,6 +1409,7 @@ extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int
 
 extern "C" int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n) {
     if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_ENTER(h);
     const int64_t have = (int64_t)h->nblk * 32;
     int rc = dsync(h->stream);
     if (rc) return rc;
@@ -1369,6 +1440,7 @@ static void p2p_release(bb_handle* h) {
 
 extern "C" int bb_p2p_export(bb_handle* h, void* handle_out) {
     if (!h || !handle_out) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     if (h->o.world_size < 2) return bb_fail(BB_ERR_INVALID, "bb_p2p_export needs a sharded handle (world_size > 1)");
     if (h->o.world_size > BB_MAX_WORLD) return bb_fail(BB_ERR_UNSUPPORTED, "at most %d ranks", BB_MAX_WORLD);
     if (h->M.kind == BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_UNSUPPORTED, "the genotype model has no resident launch");
@@ -1399,6 +1471,7 @@ extern "C" int bb_p2p_export(bb_handle* h, void* handle_out) {
 
 extern "C" int bb_p2p_import(bb_handle* h, const void* handles) {
     if (!h || !handles) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     if (!h->p2p_inbox) return bb_fail(BB_ERR_INVALID, "bb_p2p_export comes first");
     const int W = h->o.world_size;
     for (int r = 0; r < W; ++r) {
@@ -1427,6 +1500,7 @@ extern "C" int bb_p2p_import(bb_handle* h, const void* handles) {
 
 extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
     if (!h || !ok) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     *ok = 0;
     if (!h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
     const int W = h->o.world_size;
@@ -1460,6 +1534,7 @@ extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
 
 extern "C" int bb_p2p_enable(bb_handle* h, int32_t on) {
     if (!h) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     if (on && !h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
     h->p2p_on = on != 0;
     const int saved_mode = h->o.launch_mode;
@@ -1471,6 +1546,18 @@ extern "C" int bb_p2p_enable(bb_handle* h, int32_t on) {
         (void)setup_persistent(h);
         return rc ? rc : bb_fail(BB_ERR_UNSUPPORTED, "resident launch not possible on this shard");
     }
+#ifndef BB_EMU
+    if (h->p2p_on) {
+        // a zero-step launch loads the kernel's code object now (seconds on a cold process), not while the peers already poll;
+        // the first real launch still gets a longer poll limit (launch skew between the ranks' processes)
+        h->p2p_first = true;
+        const long long keep = h->req_steps;
+        rc = launch_persistent(h, 0);
+        h->req_steps = keep;
+        if (!rc) rc = dsync(h->stream);
+        if (rc) return rc;
+    }
+#endif
     return BB_OK;
 }
 
@@ -1481,6 +1568,7 @@ extern "C" int64_t bb_hier_units(const bb_handle* h) {
 
 extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* stdv) {
     if (!h || !median || !stdv) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     if (h->M.kind < BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_INVALID, "bb_hier_fitness applies to the hierarchical models only");
     if (n_samples < 2 || n_samples > 16384) return bb_fail(BB_ERR_UNSUPPORTED, "n_samples must be in 2..16384");
     if (h->o.world_size > 1) return bb_fail(BB_ERR_UNSUPPORTED, "bb_hier_fitness needs the whole posterior on one handle");
@@ -1525,6 +1613,7 @@ extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, d
 
 extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     if (!h || !s) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     memset(s, 0, sizeof *s);
     s->n_latents = h->M.D;
     s->n_moments = h->M.K;
@@ -1565,6 +1654,7 @@ extern "C" int bb_comm_make_id(void* id_out) {
 
 extern "C" int bb_comm_init(bb_handle* h, const void* id_in) {
     if (!h || !id_in) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
 #ifdef BB_EMU
     return bb_fail(BB_ERR_COMM, "no RCCL in the emulation build");
 #else
@@ -1581,6 +1671,7 @@ extern "C" int bb_comm_init(bb_handle* h, const void* id_in) {
 
 extern "C" int bb_step_moments(bb_handle* h, double* partial) {
     if (!h || !partial) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     if (h->M.kind == BB_MODEL_GENOTYPE && h->o.world_size > 1)
         return bb_fail(BB_ERR_UNSUPPORTED, "split-phase stepping of the sharded genotype model needs a second exchange; use bb_comm_init + bb_run");
     const int S = h->o.samples_per_step;
@@ -1596,6 +1687,7 @@ extern "C" int bb_step_moments(bb_handle* h, double* partial) {
 
 extern "C" int bb_step_apply(bb_handle* h, const double* total) {
     if (!h || !total) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_ENTER(h);
     const int S = h->o.samples_per_step;
     RunArgs A = make_args(h, h->step, h->sample, S, true, elbo_wanted(h, h->step));
     A.red = h->S.totals;

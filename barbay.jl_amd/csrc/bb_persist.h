@@ -86,6 +86,14 @@ struct alignas(8) bb_u2 { unsigned x, y; };
 BB_DEV bb_d2* bbp_eps(BBCtx& cx, const BBLds& L) { return (bb_d2*)(cx.lds + L.total); }
 template <int P> BB_DEV bb_u2* bbp_cnt(BBCtx& cx, const BBLds& L) { return (bb_u2*)(cx.lds + L.total + 2 * P * cx.nthr); }
 
+BB_DEV unsigned bb_get_word(const unsigned* word) {
+#ifdef BB_EMU
+    return *word;
+#else
+    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // ---- prologue: segment table, state into registers -------------------------------------------------
 template <int KIND, int P>
 BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv) {
@@ -95,7 +103,8 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
     BBSeg* sg = (BBSeg*)(lds + L.seg);
     int* li = (int*)(lds + L.misc);
     BB_PASS(cx, tid) {
-        if (tid == 0) { li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0); li[1] = 1; /* exchange ok word */ }
+        // li[1] = exchange ok word; it starts at 0 ("leave") while an earlier launch's timeout is unacknowledged by the host
+        if (tid == 0) { li[0] = bb_build_segs<KIND>(sg, M, L, t, cx.block == 0); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; }
         for (int k = tid; k < M.K + 2 * M.nt1; k += cx.nthr) lds[L.wk + k] = 0.0;
         if (KIND <= 1)      // neutral units: no own fitness, no own precision (the mutants' entries are refreshed every step)
             for (int u = tid; u < NB * bb_xdim<KIND>(M); u += cx.nthr) { lds[L.seff + u] = 0.0; lds[L.weff + u] = 0.0; }
@@ -292,7 +301,8 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
 // storing wave drains vmcnt, the workgroup meets at a barrier, ONE lane stores the row's ready word = this
 // step's epoch (sc1).  A reader polls ONLY ready words (a few lanes: polling the rows themselves from 256 CUs
 // was ~15 MB of memory-side traffic per round), then reads the row once with sc1 loads in a single batch.
-// Ready words and rows are zeroed before every launch; epochs count steps within the launch (never 0); group
+// Ready words carry base + step + 1 (RunArgs.xepoch0; never 0 on fresh memory), which only ever grows over the life of a handle --
+// no zeroing between launches, restarts bump the base; group
 // rows and their ready words are double-buffered by step parity (a slow reader of step s must not meet step
 // s+1's row); member rows need no double buffer (a member rewrites its row only after it has read every group
 // row of the previous step, which the leaders publish only after reading all member rows).  Every poll is bounded.
@@ -301,15 +311,15 @@ typedef unsigned long long bb_u64;
 BB_DEV int bbp_groups(int nblk) { return nblk < 8 ? nblk : 8; }
 
 // Poll *word until it equals epoch; false = gave up (timeout word set).
-BB_DEV bool bb_wait_word(const unsigned* word, unsigned epoch, unsigned* tmo) {
+BB_DEV bool bb_wait_word(const unsigned* word, unsigned epoch, unsigned* tmo, unsigned limit) {
 #ifdef BB_EMU
-    (void)tmo;
+    (void)tmo; (void)limit;
     return *word == epoch;           // the emulation runs the phases in order: the row must already be there
 #else
     for (unsigned spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch; ++spins) {
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 1023u) == 1023u) {
-            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 22)) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > limit) {
                 __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
@@ -362,15 +372,15 @@ BB_DEV void bb_set_word_sys(unsigned* word, unsigned v) {
     __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
-BB_DEV bool bb_wait_word_sys(const unsigned* word, unsigned epoch, unsigned* tmo) {
+BB_DEV bool bb_wait_word_sys(const unsigned* word, unsigned epoch, unsigned* tmo, unsigned limit) {
 #ifdef BB_EMU
-    (void)tmo;
+    (void)tmo; (void)limit;
     return *word == epoch;
 #else
     for (unsigned spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch; ++spins) {
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 1023u) == 1023u) {
-            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 22)) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > limit) {
                 __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
@@ -407,7 +417,7 @@ BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, c
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk), g = cx.block;
     const int members = (A.nblk - g + NG - 1) / NG;
     BB_PASS(cx, tid) {
-        if (tid < members && !bb_wait_word(S.rdy + 32 * (g + tid * NG), epoch, S.gbar + 1)) *ok = 0;
+        if (tid < members && !bb_wait_word(S.rdy + 32 * (g + tid * NG), epoch, S.gbar + 1, A.spin_limit)) *ok = 0;
     }
     BB_SYNC(cx);      // (kept although one wave does all of the leader's work when KK <= 64: letting the tile's other waves
     BB_STAMP(cx, S, 17);   //  run ahead beside that wave's dependent chain cost 2 %)
@@ -452,7 +462,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
         const unsigned* in_rdy = S.xout_rdy[A.rank] + 32ll * par * rows;
         BB_PASS(cx, tid) {
             for (int j = tid; j < rows; j += cx.nthr)
-                if (!bb_wait_word_sys(in_rdy + 32 * j, abs_epoch, S.gbar + 1)) *ok = 0;
+                if (!bb_wait_word_sys(in_rdy + 32 * j, abs_epoch, S.gbar + 1, A.spin_limit)) *ok = 0;
         }
         BB_SYNC(cx);
         BB_STAMP(cx, S, 1);
@@ -481,7 +491,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
         return;
     }
     BB_PASS(cx, tid) {
-        if (tid < NG && !bb_wait_word(S.rdy + 32 * (A.nblk + par * NG + tid), epoch, S.gbar + 1)) *ok = 0;
+        if (tid < NG && !bb_wait_word(S.rdy + 32 * (A.nblk + par * NG + tid), epoch, S.gbar + 1, A.spin_limit)) *ok = 0;
     }
     if (KK <= 64) {
         // the polling lanes and the reading lanes are one wave: it has left every poll loop before it loads (the wait
@@ -583,16 +593,17 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     BB_STAMP(cx, S, 28);
 }
 
-// ---- epilogue: state back to memory, step counter -----------------------------------------------------
+// ---- epilogue: state back to memory, step counter, status words -------------------------------------------
 template <int KIND, int P>
 BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
-                         unsigned long long step_end) {
+                         unsigned long long step_end, bool timed_out) {
     const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
     const int* li = (const int*)(lds + L.misc);
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const BBPair q = bb_pair_cached(sg, st, k);
@@ -601,7 +612,12 @@ BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const 
             bb_store_pair(S.om, q.i0, q.a0, q.a1, st.om[k]);
             bb_store_pair(S.acc_mu, q.i0, q.a0, q.a1, st.am[k]);
             bb_store_pair(S.acc_om, q.i0, q.a0, q.a1, st.ao[k]);
+            const double chk = (q.a0 ? st.mu[k].x + st.om[k].x : 0.0) + (q.a1 ? st.mu[k].y + st.om[k].y : 0.0);
+            bad = bad || !(chk - chk == 0.0);        // NaN or +-Inf anywhere in the pair's variational parameters
         }
+        // host-mapped status words (read by bb_run after the stream has drained, no copy): rare stores, any writer will do
+        if (bad) S.hstatus[1] = 1u;
+        if (timed_out && tid == 0) S.hstatus[0] = 1u;
         if (cx.block == 0 && tid == 0) { S.ctr[0] = step_end; S.ctr[1] = step_end; }
     }
     BB_SYNC(cx);
@@ -610,35 +626,41 @@ BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const 
 #ifndef BB_EMU
 template <int KIND, int P, int NT, bool XG = false>
 __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, const BBLds* __restrict__ Lp,
-                                                  RunArgs A, int NB, unsigned long long step0, int nsteps) {
+                                                  RunArgs A, int NB, int nsteps) {
     const DevModel& M = *Mp;   // descriptors live in device memory: scalar loads on demand instead of ~1.5 KB of
     const DevState& S = *Sp;   // kernel arguments held (and spilled) in SGPRs across the whole step loop
     extern __shared__ __attribute__((aligned(16))) double bbp_smem[];
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bbp_smem, NT > 512 ? (const void*)Lp : nullptr};
     BBPst<P> st;
     int* ok_slot = (int*)(bbp_smem + Lp->misc) + 1;
+    // the step comes from the device counter, not from the host: launches of one bb_run queue back to back, and one that
+    // follows a timed-out launch must neither skip steps nor run at all (the timeout word stays set until the host clears it)
+    const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
+    const unsigned long long step0 = c0 > c1 ? c0 : c1;   // (the two-kernel step ping-pongs the counter: the current step is the larger word)
     bbp_prologue<KIND, P>(cx, M, S, A, NB, &st);
-    bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step0);
+    const bool dead = *ok_slot == 0;               // uniform: written by one thread before the prologue's barriers
     int done = 0;
+    if (!dead) {
+    bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step0);
     for (; done < nsteps; ++done) {
         const unsigned long long step = step0 + (unsigned long long)done;
         bbp_sample<KIND, P>(cx, M, S, A, NB, &st, step);
         {
             const BBLds L = bbp_layout<KIND>(cx, M, NB);
-            const unsigned epoch = (unsigned)(done + 1);
-            const unsigned abs_epoch = A.xepoch0 + (unsigned)(step + 1);   // inbox words of the cross-GPU leg never restart
+            const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);   // ready / inbox words never restart
             const int par = (int)(step & 1);
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
             bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight
-            if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
+            if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);
             bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
             bbp_residual_ahead<KIND>(cx, M, NB, A);                    // ... and the totals-independent half of the residuals is tabulated
-            bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, abs_epoch);
+            bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);
             bbp_finish<KIND>(cx, M, S, A, NB);
             if (*ok_slot == 0) break;                                  // uniform: read after the F pass's barrier
         }
         bbp_update<KIND, P>(cx, M, S, A, NB, &st, step);
     }
-    bbp_epilogue<KIND, P>(cx, M, S, A, NB, &st, step0 + (unsigned long long)done);
+    }
+    bbp_epilogue<KIND, P>(cx, M, S, A, NB, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
 }
 #endif

@@ -68,7 +68,8 @@ struct DevState {
     double *elbo_sample;              // [S]
     unsigned long long *ctr;          // [2] device-side step counter (ping-pong)
     const double *eps_in;             // [S][D] caller-supplied draws (test hook) or nullptr
-    unsigned *gbar;                   // [32 * 10] exchange counters of the persistent launch (one 128-B line each)
+    unsigned *gbar;                   // [32 * 10] words of the persistent launch, one 128-B line each: [1] = timeout word (sticky until the host clears it)
+    unsigned *hstatus;                // host-mapped status words the host reads after a run without a copy: [0] timeout, [1] non-finite state
     double *prow;                     // [nblk][K + 2 nt1] rows of the tiles (persistent launch)
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
@@ -86,7 +87,8 @@ struct DevState {
 struct RunArgs {
     long long b_lo, b_hi;             // barcode shard [b_lo, b_hi)
     int rank, world;                  // of the sharded run (0, 1 otherwise)
-    unsigned xepoch0;                 // base of the cross-GPU inbox words (bb_persist.h)
+    unsigned xepoch0;                 // base of the ready / inbox words of the resident launch: they carry base + step + 1 and only ever grow (bb_persist.h)
+    unsigned spin_limit;              // polls of one ready word before a resident launch gives up (the first launch of a sharded run gets more)
     int nblk;                         // blocks of the barcode grid
     int par;                          // which ctr[] word holds the current step
     int sample, S;

@@ -34,6 +34,56 @@ def cpu_baseline(wl, seconds_budget: float = 20.0):
     return port.time_workload(wl, port.usable_cores(), seconds_budget)
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one per GPU, each re-running this file with
+    the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  The parent touches no GPU and imports no torch;
+    it relays rank 0's JSON line and returns the worst exit status.  If a rank dies the others are ended (by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().splitlines()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        live = list(procs)
+        while live:                                   # a rank that dies must not leave the others waiting at a barrier
+            time.sleep(0.2)
+            for p in list(live):
+                if p.poll() is not None:
+                    live.remove(p)
+                    if p.returncode != 0 and rc == 0:
+                        rc = p.returncode
+                        print(f"[bench] rank {procs.index(p)} exited with status {p.returncode}; ending the other ranks", file=sys.stderr)
+                        for q in live:
+                            q.kill()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    reader.join(timeout=10)
+    line = None
+    for ln in lines:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is None:
+        return rc or 1
+    print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +95,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=200, help="eagerly launched steps timed per kernel for `roofline`")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only spawns and waits (it never imports torch nor touches a GPU)
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -61,6 +115,11 @@ def main():
     rehearsal = world > 1 and os.environ.get("BB_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        # all ranks' resident launches must be co-resident on the ONE device: 256 / world tiles of 1024 threads per rank
+        # (one 1024-thread workgroup fills a CU's register file; the engine sizes tiles for a whole GPU per rank otherwise)
+        per_rank = -(-args.barcodes // world)
+        os.environ.setdefault("BB_TUNE_NB", str(-(-per_rank // max(256 // world, 1))))
+        os.environ.setdefault("BB_TUNE_NTHR", "1024")
     torch.cuda.set_device(local_rank)
     tdev = "cpu" if rehearsal else "cuda"
     if world > 1:
@@ -110,7 +169,10 @@ def main():
         eng.run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    eng.run(args.steps)          # returns after the engine's stream has drained
+    try:
+        eng.run(args.steps)      # returns after the engine's stream has drained
+    except bb._capi.BarBayNonFinite as err:       # the steps were taken; reported below as posterior_finite = false
+        print(f"[rank {rank}] {err}", file=sys.stderr, flush=True)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -137,7 +199,8 @@ def main():
         steps_per_launch = args.steps / launches
         launch_s = st["last_run_ms"] * 1e-3 / launches
         ach = st["bytes_per_step"] * steps_per_launch / launch_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_persist", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_persist", "kernel_instance": f"k_persist<{bb._capi.BB_MODEL[wl.kind]}, {int(st['persistent_pairs'])}, {1024 if int(st['block_threads']) > 512 else 512}",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(st["bytes_per_step"] * steps_per_launch),
                     "algorithmic_bytes_per_step": int(st["bytes_per_step"]), "steps_per_launch": steps_per_launch,
@@ -156,16 +219,35 @@ def main():
     if roofline is not None and world > 1:
         roofline["scope"] = "rank 0's GPU and its shard of the bytes"
     if roofline is not None and world == 1:
+        # `traffic` is NOT measured in this run (PMC counters need rocprofv3 around the process): it is REPLAYED from the last
+        # committed counter passes of the same kernel, and only while the device sources are still the ones profiled
         tr = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        why = "profiles/hbm_traffic_latest.json missing"
         if os.path.exists(tr):
             try:
+                from tools.hbm_traffic import csrc_sha
                 t = json.load(open(tr))
-                if t.get("kernel") == roofline["kernel"]:
-                    per_step = t["hbm_bytes_per_step"]
-                    roofline["traffic"] = int(per_step * roofline.get("steps_per_launch", 1))
+                inst = str(t.get("kernel_instance", ""))
+                want_inst = roofline.get("kernel_instance", roofline["kernel"])
+                if t.get("kernel") != roofline["kernel"] or (roofline.get("kernel_instance") and want_inst.replace(" ", "") not in inst.replace(" ", "")):
+                    why = f"counter passes are of {inst or t.get('kernel')}, this run's kernel is {want_inst}"
+                elif t.get("csrc_sha") != csrc_sha():
+                    why = "device sources changed since the counter passes were taken (csrc hash differs)"
+                else:
+                    per_step = float(t["hbm_bytes_per_step"])
+                    spl = roofline.get("steps_per_launch", 1)
+                    roofline["traffic"] = int(per_step * spl)
+                    roofline["traffic_source"] = (f"replayed, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                  f"'{t.get('source')}' of {inst}, {t.get('steps_in_launch')} steps per launch, scaled per step")
+                    roofline["traffic_steps_in_launch"] = t.get("steps_in_launch")
                     roofline["traffic_note"] = t.get("note")
-            except Exception:
-                pass
+                    # counter bytes over the measured launch time: what actually crossed the memory side, against the peak
+                    roofline["hbm_side_frac"] = round(per_step * spl / (roofline["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    why = None
+            except Exception as err:      # a broken profile file must not take the bench line with it
+                why = f"unreadable: {err}"
+        if why:
+            roofline["traffic_source"] = f"none ({why})"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

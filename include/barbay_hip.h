@@ -31,6 +31,9 @@ extern "C" {
 #define BB_ERR_DEVICE (-2)    /* HIP runtime error                           */
 #define BB_ERR_COMM (-3)      /* RCCL error / communicator not initialised   */
 #define BB_ERR_UNSUPPORTED (-4)
+#define BB_ERR_NONFINITE (-5) /* bb_run: the steps were taken, but the variational parameters (or the exchanged
+                                 moments) went NaN / Inf on the way -- the reference has no such guard and would
+                                 return the NaN posterior silently                      */
 
 /* model kinds: BarBay.model.* entries on the hot path */
 #define BB_MODEL_FITNESS 0    /* fitness_normal            src/model_fitness_normal.jl:120-272 */

@@ -281,9 +281,10 @@ int port_run(const port_model* M, double* mu, double* omega, int64_t first_step,
                 double* acc = state + (int64_t)window * 2 * D;
                 const double n2 = d * d, old = hist[(int64_t)slot * 2 * D + j];
                 hist[(int64_t)slot * 2 * D + j] = n2;
-                double sacc;
-                if (resum) { sacc = 0.0; for (int k = 0; k < window; ++k) sacc += hist[(int64_t)k * 2 * D + j]; }
-                else sacc = fmax(acc[j] + n2 - old, 0.0);
+                /* running sum; an element whose difference cancelled more than 24 bits is re-added exactly (engine: bb_opt_apply) */
+                const double t = acc[j] + n2;
+                double sacc = t - old;
+                if (resum || t > 0x1p24 * sacc) { sacc = 0.0; for (int k = 0; k < window; ++k) sacc += hist[(int64_t)k * 2 * D + j]; }
                 acc[j] = sacc;
                 upd = d * (eta / (tau + sqrt(sacc)));
             } else {

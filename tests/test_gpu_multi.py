@@ -1,0 +1,116 @@
+"""GPU, >= 2 physical devices (skipped on the one-GPU boxes): the sharded run over REAL peers, both exchange paths --
+(a) two kernels + ncclAllReduce of the K moment rows (RCCL over xGMI), (b) the resident launch with the group rows pushed
+into peer-mapped inboxes -- each against the unsharded run, with the replicated global latents bit-identical on all ranks;
+and `python bench.py --gpus N` started as a plain process (it spawns its own ranks)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, steps, p2p, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import barbay_jl_amd as bb
+    import _cases as c
+    from conftest import make_engine
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    sp = c.synth(case, seed=4)
+    e = make_engine(sp, None, seed=5, window=4, resum_every=1, rank=rank, world_size=world, device=rank)
+    bb.dist.init_rccl(e)
+    on = bb.dist.setup_p2p(e) if p2p else False
+    for _ in range(2):                      # the second pass restarts with the inboxes still holding the first's words
+        e.init_meanfield()
+        e.run(3)
+        e.run(steps - 3)
+    mean, sigma = bb.dist.gather_posterior(e, sp.kind, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env)
+    lay = {n: (lo, hi) for n, lo, hi in e.layout()}
+    glo, ghi = lay["s_pop"][0], lay["logsigma_pop"][1]
+    m_own, s_own = e.posterior()
+    copies = [None] * world
+    dist.all_gather_object(copies, (m_own[glo:ghi].tobytes(), s_own[glo:ghi].tobytes()))
+    st = e.stats()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "sharded.npz"), mean=mean, sigma=sigma, on=on, pairs=st["persistent_pairs"],
+                 identical=all(cp == copies[0] for cp in copies))
+    dist.barrier()
+    e.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("p2p", [False, True], ids=["rccl", "xgmi_inbox"])
+@pytest.mark.parametrize("case", ["fitness_multi_tile", "replicate_ragged"])
+def test_sharded_over_real_peers(hip_lib, tmp_path, monkeypatch, case, p2p):
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch.multiprocessing as mp
+    import _cases as c
+    from conftest import make_engine
+    world = min(_n_gpus(), 4)
+    monkeypatch.setenv("BB_TUNE_NB", "8")           # >= 8 tiles per rank at 4 ranks (the resident launch's minimum)
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    steps = 50
+    sp = c.synth(case, seed=4)
+    with make_engine(sp, hip_lib, seed=5, window=4, resum_every=1, launch_mode=1) as e1:
+        e1.run(steps)
+        m1, s1 = e1.posterior()
+    mp.spawn(_worker, args=(world, _free_port(), case, steps, p2p, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    if p2p:
+        assert bool(got["on"]) and int(got["pairs"]) == 1          # the resident launch over peer-mapped inboxes really ran
+    assert bool(got["identical"])                                   # replicated global latents: bit-identical on all ranks
+    assert np.abs(got["mean"] - m1).max() < 1e-8 and np.abs(got["sigma"] - s1).max() < 1e-8
+
+
+@pytest.mark.parametrize("flags", [[], ["--no-p2p"]], ids=["resident", "rccl"])
+def test_bench_spawns_its_own_ranks(flags):
+    """`python bench.py --gpus N` as the driver starts it at N = 1: no launcher, no WORLD_SIZE."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10",
+                        "--no-cpu-baseline"] + flags, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["posterior_finite"] and out["replicated_latents_identical_on_all_ranks"]
+    assert out["value"] > 0
+
+
+def test_bench_rehearsal_two_ranks_on_one_gpu():
+    """One-GPU boxes: `BB_BENCH_REHEARSAL=1 python bench.py --gpus 2` (plain process, self-spawned ranks, both on device 0,
+    gloo for the votes, the resident launch's inboxes through hipIpc) must print its one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["BB_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["posterior_finite"] and out["replicated_latents_identical_on_all_ranks"]
+    assert "resident launch" in out["config"]["collective"]

@@ -23,21 +23,34 @@ def counter_rows(d):
 
 
 def per_dispatch(rows, counter, kernel):
-    vals = {}
+    vals, names = {}, {}
     for r in rows:
         if r.get("Counter_Name") == counter and kernel in r.get("Kernel_Name", ""):
             vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-    return vals
+            names[r["Dispatch_Id"]] = r["Kernel_Name"]
+    return vals, names
+
+
+def csrc_sha():
+    """Content hash of the device sources: bench.py attaches the replayed traffic figure only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "barbay.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main(fetch_dir, write_dir, kernel, steps, tag):
-    f = per_dispatch(counter_rows(fetch_dir), "FETCH_SIZE", kernel)
-    w = per_dispatch(counter_rows(write_dir), "WRITE_SIZE", kernel)
+    f, fn = per_dispatch(counter_rows(fetch_dir), "FETCH_SIZE", kernel)
+    w, _ = per_dispatch(counter_rows(write_dir), "WRITE_SIZE", kernel)
     if not f or not w:
         raise SystemExit(f"no {kernel} rows: fetch {len(f)} write {len(w)}")
     fk, wk = max(f.values()), max(w.values())        # the timed launch is the longest one
+    instance = fn[max(f, key=f.get)].split("(")[0]
     fetch_b, write_b = 2.0 * fk * 1024.0, wk * 1024.0
-    out = {"kernel": kernel, "steps_in_launch": steps, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+    out = {"kernel": kernel, "kernel_instance": instance, "csrc_sha": csrc_sha(), "steps_in_launch": steps, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
            "hbm_bytes_per_step": (fetch_b + write_b) / steps, "fetch_bytes_per_step": fetch_b / steps,
            "write_bytes_per_step": write_b / steps,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled (gfx950 "
