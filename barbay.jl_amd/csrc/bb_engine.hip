@@ -10,6 +10,7 @@
 #include "../../include/barbay_hip.h"
 #include "bb_block.h"
 #include "bb_persist.h"
+#include "bb_resident.h"
 #include "bb_hier.h"
 
 #include <algorithm>
@@ -249,6 +250,9 @@ struct bb_handle {
     bb_ncclComm_t comm = nullptr;
 #endif
     int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
+    int res_P = 0;                     // > 0: the launch is k_res (bb_resident.h, owner-computes) with this many pair slots per thread
+    BRLay Yh{};                        // its LDS carve-up (host copy) and device copy
+    BRLay* dY = nullptr;
     DevModel* dM = nullptr;            // device copies of the descriptors for the persistent launch
     DevState* dS = nullptr;
     BBLds* dL = nullptr;               // ... and of the resident launch's LDS carve-up (host copy: Lp)
@@ -381,6 +385,28 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = fal
 }
 #endif
 
+#ifndef BB_EMU
+typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
+static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg) {
+#define BR_CASE(K, PP, NT) case (K) * 10 + (PP): return xg ? k_res<K, PP, NT, true> : k_res<K, PP, NT, false>;
+    if (nthr > 512) {          // 16 waves per CU: 128 registers per lane
+        switch (kind * 10 + P) { BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) default: return nullptr; }
+    }
+    if (nthr > 256) {          // 8 waves per CU: 256 registers per lane
+        switch (kind * 10 + P) {
+            BR_CASE(0, 1, 512) BR_CASE(0, 2, 512) BR_CASE(0, 3, 512) BR_CASE(1, 1, 512) BR_CASE(1, 2, 512) BR_CASE(1, 3, 512)
+            default: return nullptr;
+        }
+    }
+    switch (kind * 10 + P) {   // 4 waves per CU: 512 registers per lane
+        BR_CASE(0, 1, 256) BR_CASE(0, 2, 256) BR_CASE(0, 3, 256) BR_CASE(0, 4, 256)
+        BR_CASE(1, 1, 256) BR_CASE(1, 2, 256) BR_CASE(1, 3, 256) BR_CASE(1, 4, 256)
+        default: return nullptr;
+    }
+#undef BR_CASE
+}
+#endif
+
 // pairs a tile can hold: every segment contributes count/2 + 1 at most
 static long long tile_pairs_bound(const DevModel& M, long long NB) {
     long long p = 0;
@@ -399,7 +425,35 @@ static int sync_descriptors(bb_handle* h) {
     if (!h->dM && ((rc = dalloc(h, &h->dM, 1)) || (rc = dalloc(h, &h->dS, 1)) || (rc = dalloc(h, &h->dL, 1)))) return rc;
     if ((rc = h2d(h->dM, &h->M, sizeof(DevModel), h->stream)) || (rc = h2d(h->dS, &h->S, sizeof(DevState), h->stream))) return rc;
     h->Lp = bb_lds_layout(h->M.R, h->M.E, h->M.kind, h->M.Ttot, h->M.nt1, h->M.K, h->NB, h->nthr, 1);   // the resident launch's carve-up
-    return h2d(h->dL, &h->Lp, sizeof(BBLds), h->stream);
+    if ((rc = h2d(h->dL, &h->Lp, sizeof(BBLds), h->stream))) return rc;
+    if (!h->dY && (rc = dalloc(h, &h->dY, 1))) return rc;
+    return h2d(h->dY, &h->Yh, sizeof(BRLay), h->stream);
+}
+
+// the owner-computes launch (bb_resident.h) where the shape allows it; BB_NO_RES=1 keeps k_persist (A/B runs)
+static bool try_resident(bb_handle* h) {
+    const char* ev = getenv("BB_NO_RES");
+    if (ev && atoi(ev) > 0) return false;
+    if (!br_eligible(h->M)) return false;
+    const int P = (int)((br_tile_span(h->M, h->NB, true) + h->nthr - 1) / h->nthr);
+    if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
+    const BRLay Y = br_layout(h->M, h->NB, h->nthr, P);
+    if ((size_t)Y.total * 8 > 160 * 1024) return false;
+    if (P * (h->nthr / 64) >= 1024) return false;               // row map packs virtual-wave numbers into 10 bits
+#ifndef BB_EMU
+    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on);
+    if (!k) return false;
+    const int lds = Y.total * 8;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+    int per_cu = 0;
+    hipDeviceProp_t pr;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, h->nthr, (size_t)lds) != hipSuccess ||
+        hipGetDeviceProperties(&pr, h->o.device) != hipSuccess || (long long)per_cu * pr.multiProcessorCount < h->nblk) return false;
+#endif
+    h->Yh = Y;
+    h->res_P = P;
+    h->lds_doubles_p = (size_t)Y.total;
+    return true;
 }
 
 static int setup_persistent(bb_handle* h) {
@@ -412,6 +466,8 @@ static int setup_persistent(bb_handle* h) {
     else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";
     else if (h->o.elbo_every != 0) why = "ELBO recording is on";
     else if (h->M.kind == BB_MODEL_GENOTYPE) why = "genotype model (second exchange per step)";
+    h->res_P = 0;
+    if (!why && want && try_resident(h)) { h->persist_P = h->res_P; return 0; }
     int P = 0;
     if (!why) {
         P = (int)((tile_pairs_bound(h->M, h->NB) + h->nthr - 1) / h->nthr);
@@ -507,7 +563,54 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     }
 }
 
+template <int KIND, int PP>
+static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nsteps) {
+    bb_handle* h = E.h;
+    const RunArgs& A = E.A;
+    BRSt<PP>* st = (BRSt<PP>*)E.st.data();
+    auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), nullptr}; };
+    const BRLay& Y = h->Yh;
+    const unsigned long long step = (unsigned long long)(h->step + it);
+    const int buf = (int)(step & 1);
+    const bool xg = h->p2p_on;
+    for (int b = 0; b < (phase == 2 ? bbp_groups(h->nblk) : h->nblk); ++b) {
+        BBCtx cx = cxof(b);
+        BRSt<PP>* sb = st + (size_t)b * h->nthr;
+        if (phase == 0) {
+            br_prologue<KIND, PP>(cx, h->M, h->S, A, Y, h->NB, sb);
+            br_draw_ahead<PP>(cx, A, Y, sb, (unsigned long long)h->step);
+        } else if (phase == 1) {
+            br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
+            br_moments<KIND, PP>(cx, h->M, h->S, Y, sb, buf);
+            br_xchg_publish<PP>(cx, h->M, h->S, A, Y, sb, step);
+        } else if (phase == 2) {
+            if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);
+            else br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
+        } else if (phase == 3) {
+            if (xg) br_xchg_consume<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
+            else br_xchg_consume<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
+            br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf);
+        } else {
+            br_epilogue<PP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
+        }
+    }
+}
+
 static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long long nsteps) {
+    if (E.h->res_P) {
+        auto byP = [&](auto kindc) {
+            constexpr int KIND = decltype(kindc)::value;
+            switch (E.h->res_P) {
+            case 1: emu_res_phase<KIND, 1>(E, phase, it, nsteps); break;
+            case 2: emu_res_phase<KIND, 2>(E, phase, it, nsteps); break;
+            case 3: emu_res_phase<KIND, 3>(E, phase, it, nsteps); break;
+            default: emu_res_phase<KIND, 4>(E, phase, it, nsteps);
+            }
+        };
+        if (E.h->M.kind == 0) byP(std::integral_constant<int, 0>{});
+        else byP(std::integral_constant<int, 1>{});
+        return;
+    }
     auto byP = [&](auto kindc) {
         constexpr int KIND = decltype(kindc)::value;
         switch (E.h->persist_P) {
@@ -525,6 +628,9 @@ static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long lo
     }
 }
 
+static size_t emu_rst_bytes(int P) {
+    return P == 1 ? sizeof(BRSt<1>) : (P == 2 ? sizeof(BRSt<2>) : (P == 3 ? sizeof(BRSt<3>) : sizeof(BRSt<4>)));
+}
 static size_t emu_pst_bytes(int P) {
     return P == 1 ? sizeof(BBPst<1>) : (P == 2 ? sizeof(BBPst<2>) : (P == 3 ? sizeof(BBPst<3>) : sizeof(BBPst<4>)));
 }
@@ -536,7 +642,7 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
         es[i].h = h;
         es[i].A = make_args(h, h->step, 0, 1, true, false);
         es[i].lds.assign((size_t)h->nblk * (h->lds_doubles_p + 64), 0.0);
-        es[i].st.assign((size_t)h->nblk * h->nthr * emu_pst_bytes(h->persist_P), 0);
+        es[i].st.assign((size_t)h->nblk * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
     }
     for (long long it = 0; it < nsteps; ++it)
@@ -573,11 +679,13 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // No per-launch memsets: ready words carry base + step + 1 and only grow; the timeout word is sticky (a launch that finds it
     // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
     // first step from the device counter.
-    bb_persist_kernel k = persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
+    bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
+    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on) : nullptr;
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
-        hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB, n);
+        if (kr) hipLaunchKernelGGL(kr, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->NB, n);
+        else hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB, n);
         rc = launch_check();
         h->step += n;
         nsteps -= n;
@@ -1544,8 +1652,10 @@ extern "C" int bb_p2p_enable(bb_handle* h, int32_t on) {
     if (rc || (h->p2p_on && h->persist_P == 0)) {
         h->p2p_on = false;
         (void)setup_persistent(h);
+        (void)sync_descriptors(h);
         return rc ? rc : bb_fail(BB_ERR_UNSUPPORTED, "resident launch not possible on this shard");
     }
+    if ((rc = sync_descriptors(h))) return rc;
 #ifndef BB_EMU
     if (h->p2p_on) {
         // a zero-step launch loads the kernel's code object now (seconds on a cold process), not while the peers already poll;
@@ -1631,6 +1741,7 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->lds_bytes = (int32_t)((h->persist_P > 0 ? h->lds_doubles_p : h->lds_doubles) * 8);
     s->persistent_pairs = h->persist_P;
     s->launches_last_run = h->launches_last_run;
+    s->resident_kernel = h->res_P > 0 ? 2 : (h->persist_P > 0 ? 1 : 0);
     return BB_OK;
 }
 

@@ -1,0 +1,716 @@
+// bb_resident.h -- the ADVI step loop as one resident launch, second generation: the OWNER of a latent computes.
+//
+// k_persist (bb_persist.h) keeps theta in registers but still runs the (barcode, time) work as separate passes over
+// LDS-staged tables: a step is ~12 workgroup barriers, and the S -> M and R/U -> G hand-offs go through LDS.  Here the
+// thread that owns a pair of consecutive loglambda latents (b, t), (b, t+1) also does that pair's (b, t) work:
+//
+//   S  softplus / sigmoid, z = mu + sigma eps, lambda = e^z; z goes to LDS only for the two NEIGHBOUR pairs of the barcode
+//      (they need l[t-1], l[t+2]) and for the per-unit gradient sums; unit latents (s_bc, logsigma_bc, ...) are staged in
+//      the form their readers need (s raw, precision w = e^{-2 logsigma})
+//   -- barrier 1 --
+//   M  differences, a = dl - s_eff, the pair's moment contributions; lanes of a wave with the same time pair are summed
+//      by a shuffle butterfly, one lane per (wave, time pair) leaves 12 partial sums in LDS
+//   -- barrier 2 --
+//      K row entries = fixed-order sums over the waves; the row is published straight from registers
+//   X  exchange (bb_persist.h: tiles -> 8 group leaders -> every tile; cross-GPU inboxes when sharded); in its shadow the
+//      next step's normals and the window-slot prefetch, as before
+//   F  c_t, D_t, G_t/S_t, global-latent gradients -- ends with barrier 3
+//   G  gradient of the pair's latents from REGISTERS (lambda, a, w) + a handful of per-time table reads, prior,
+//      optimiser, window slot
+//
+// Three workgroup barriers per step (+ the leaders' two).  LDS tables that a later phase of the SAME step still reads
+// while fast waves already write the next step's values (z, unit stages) are double-buffered by step parity.
+//
+// Lane mapping: every loglambda segment (one per replicate) starts at a wave boundary; LPB = pow2 >= T/2 lanes per
+// barcode, lane = bl * LPB + k owns (b, 2k), (b, 2k+1); k >= T/2 idles (T = 6: one lane in four).  All lanes of a wave with
+// equal lane % LPB feed the same moment rows, so the wave-level sum is a butterfly over the upper lane bits.  Unit pairs
+// follow, flat.  Needs: every T_r even and <= 16, the loglambda block starting at an even flat index (pairs then never
+// straddle barcodes), not the ragged-method quirk; other shapes keep k_persist.
+//
+// Written, like bb_persist.h, as passes over an explicit per-thread state so that the host emulation (tests) runs the
+// same source; the only wave-level operation (the butterfly) has an emulation twin that adds the same numbers.
+#pragma once
+#include "bb_persist.h"
+
+#define BR_NCV 12          // per pair: 2 time slots x (S, M0, M1, M2, N1, N2)
+// Scheduling fence: the two latents of a pair run the same long fp64 chains (softplus / sigmoid / exp / sqrt / rcp); interleaved for
+// ILP they double the live temporaries and the 128-VGPR budget of a 16-wave workgroup spills.  Four waves per SIMD hide the
+// dependent-issue latency anyway, so the chains are kept one after the other.
+#if defined(BB_EMU)
+#define BR_SCHED_FENCE() ((void)0)
+#else
+#define BR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define BR_MAXT 16
+
+struct BRSeg { long long lo, hi; int tbeg, span, blk, kind, ldsoff, r, lpb, T; };   // 48 B = 6 doubles
+
+struct BRLay {
+    BBLds L;             // what the shared exchange / finish code reads: wk, zgl, Lt, invS, cc, wbar, gglob, Dt, elbt, misc, acc, red
+    int zl, NBT;         // [2][NBT] staged loglambda samples (NBT = NB * Ttot), double-buffered by step parity
+    int st[4], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w
+                         //                                  hierarchical        0 = theta_tilde, 1 = e^logtau, 2 = w, 3 = theta
+    int eps;             // [P * NT] bb_d2: the next step's normals
+    int wpart, wstride;  // [V][wstride] wave partial sums, wstride = 12 * max LPB
+    int rowmap;          // [K] ints: vbeg | vend << 10 | off << 20
+    int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
+    int seg;             // BRSeg table
+    int total;
+    int lpb[BB_MAX_REP];
+};
+
+static inline int br_pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// padded thread-index span of a tile: loglambda segments wave-aligned, LPB lanes per barcode, then the unit pairs
+static inline long long br_tile_span(const DevModel& M, long long NB, bool globals) {
+    long long p = 0;
+    for (int r = 0; r < M.R; ++r) p = ((p + 63) & ~63ll) + NB * br_pow2_ge(M.T[r] / 2);
+    if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
+    else if (M.kind == 2) p += 3 * (NB / 2 + 1);
+    else if (M.kind == 3) p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
+    else p += (NB * M.E / 2 + 1) + 3ll * M.R * (NB * M.E / 2 + 1);
+    if (globals) p += 2 * (M.nt1 / 2 + 1);
+    return p;
+}
+
+static inline bool br_eligible(const DevModel& M) {
+    if (M.kind != 0 && M.kind != 1) return false;
+    if (M.quirk || M.Ttot > 64) return false;
+    for (int r = 0; r < M.R; ++r) if ((M.T[r] & 1) || M.T[r] > BR_MAXT) return false;
+    if (M.blk_lo[BK_L] & 1) return false;
+    for (int r = 0; r < M.R; ++r) if (M.off_l[r] & 1) return false;
+    return true;
+}
+
+static inline
+#ifndef BB_EMU
+__host__ __device__
+#endif
+BRLay br_layout(const DevModel& M, int NB, int NT, int P) {
+    BRLay Y;
+    const int X = (M.kind == 1) ? M.E : (M.kind == 4 ? M.E * M.R : M.R);
+    const int KK = M.K + 2 * M.nt1;
+    int o = 0;
+    int lmax = 1;
+    for (int r = 0; r < BB_MAX_REP; ++r) { Y.lpb[r] = r < M.R ? br_pow2_ge(M.T[r] / 2) : 1; if (Y.lpb[r] > lmax) lmax = Y.lpb[r]; }
+    BBLds& L = Y.L;
+    L = BBLds{};
+    Y.NBT = NB * M.Ttot;
+    Y.zl = o;      o += 2 * Y.NBT;
+    Y.SU = NB * X;
+    Y.nst = M.kind <= 1 ? 2 : 4;
+    for (int i = 0; i < 4; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
+    o = (o + 1) & ~1;
+    Y.eps = o;     o += 2 * P * NT;
+    Y.wstride = BR_NCV * lmax;
+    Y.wpart = o;   o += P * (NT / 64) * Y.wstride;
+    Y.rowmap = o;  o += (M.K + 1) / 2 + 1;
+    L.wk = o;      o += KK;
+    L.zgl = o;     o += 2 * M.nt1;
+    L.Lt = o;      o += M.Ttot;
+    L.invS = o;    o += M.Ttot;
+    L.cc = o;      o += M.Ttot + 1;
+    L.GG = o;
+    L.wbar = o;    o += M.Ttot + 1;
+    L.gglob = o;   o += 2 * M.nt1;
+    L.misc = o;    o += 16 + BB_MAX_REP;
+    L.part = o;    o += 32;
+    L.Dt = o;      o += M.Ttot + 1;
+    L.elbt = o;    o += M.Ttot;
+    Y.iG = o;      o += M.Ttot;
+    Y.csum = o;    o += BB_MAX_REP;
+    Y.seg = o;     o += 6 * (BB_MAX_SEG + 1);
+    L.seg = Y.seg;
+    o = (o + 1) & ~1;
+    L.acc = o;     o += (BB_NQ + 1) * NT;      // staging of the cross-GPU inbox rows (bbp_consume<true>)
+    L.red = o;     o += KK + 16;
+    L.total = Y.total = (o + 1) & ~1;
+    return Y;
+}
+
+template <int P>
+struct BRSt {
+    bb_d2 mu[P], om[P], am[P], ao[P];   // variational parameters and optimiser accumulators
+    bb_d2 a[P], h[P];                   // eps * sigmoid(omega), sigmoid / softplus of the current draw
+    bb_d2 hm[P], ho[P];                 // this step's window slot (prefetched during the exchange)
+    bb_d2 z[P];                         // the pair's samples
+    bb_d2 lam[P];                       // loglambda pairs: e^z
+    double ap[P], amid[P], an[P];       // loglambda pairs: a = dl - s_eff of the backward / inner / forward difference
+    double wp[P], wm[P], wn[P];         // ... and the mutant's precisions there
+    double cv[P][BR_NCV];               // moment contributions (alive between the M pass and the wave sum)
+    long long i0[P];
+    int meta[P];                        // seg kind | a0 << 4 | a1 << 5 | valid << 6 | mutant << 7 | has_prev << 8 | has_next << 9 | seg index << 12
+    int zoff[P];                        // loglambda: offset of z0 inside one zl buffer; unit pairs: index of latent 0 inside its stage table
+    int uo[P][3];                       // loglambda, mutant: stage-table index of the unit the backward / inner / forward difference uses;
+                                        // unit pairs: [0], [1] = zl-buffer offset of the barcode row of latent 0 / 1, [2] = env of latent 0 | env of latent 1 << 8
+    int pt[P];                          // loglambda: tcum[r] + t0; unit pairs: tcum[r]
+    unsigned cnt[P][2];                 // loglambda: the two counts
+    int wl[P];                          // LPB of the loglambda segment that covers this thread's WAVE in pair slot k (0: none) -- wave-uniform
+};
+
+enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
+
+// ---- segment table of a tile in the padded thread-index space (one thread) --------------------------------------
+template <int KIND>
+BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTile& t, bool globals) {
+    int n = 0, cur = 0;
+    auto add = [&](int blk, int kind, long long lo, long long cnt, int ldsoff, int r, int lpb, int T) {
+        if (cnt <= 0) return;
+        BRSeg s;
+        s.lo = lo; s.hi = lo + cnt; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.lpb = lpb; s.T = T;
+        if (kind == SK_L) { cur = (cur + 63) & ~63; s.span = (int)(cnt / T) * lpb; }
+        else s.span = bb_seg_pairs(lo, lo + cnt);
+        s.tbeg = cur;
+        cur += s.span;
+        sg[n++] = s;
+    };
+    for (int r = 0; r < M.R; ++r)
+        add(BK_L, SK_L, M.off_l[r] + t.b0 * M.T[r], (long long)t.nbt * M.T[r], t.NB * M.tcum[r], r, Y.lpb[r], M.T[r]);
+    if (t.nmt > 0) {
+        if (KIND == 0 || KIND == 1) {
+            const int E = KIND == 1 ? M.E : 1;
+            add(BK_S, SK_S, M.blk_lo[BK_S] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, 0);
+            add(BK_LS, SK_LS_E, M.blk_lo[BK_LS] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, 0);
+        }
+    }
+    if (globals) {
+        add(BK_SPOP, SK_GS, M.blk_lo[BK_SPOP], M.blk_hi[BK_SPOP] - M.blk_lo[BK_SPOP], 0, 0, 0, 0);
+        add(BK_LSPOP, SK_GLS, M.blk_lo[BK_LSPOP], M.blk_hi[BK_LSPOP] - M.blk_lo[BK_LSPOP], 0, 0, 0, 0);
+    }
+    sg[n].tbeg = cur;
+    return n;
+}
+
+// ---- prologue: segment table, row map, per-thread metadata, state into registers --------------------------------
+template <int KIND, int P>
+BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, BRSt<P>* stv) {
+    double* lds = cx.lds;
+    const BBLds& L = Y.L;
+    const BBTile t = bb_tile(M, A, cx.block, NB);
+    BRSeg* sg = (BRSeg*)(lds + Y.seg);
+    int* li = (int*)(lds + L.misc);
+    const int KK = M.K + 2 * M.nt1;
+    BB_PASS(cx, tid) {
+        // li[1] = exchange ok word; it starts at 0 ("leave") while an earlier launch's timeout is unacknowledged by the host
+        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; }
+        for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
+        for (int i = tid; i < 2 * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
+        for (int i = tid; i < 2 * Y.nst * Y.SU; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
+        for (int i = tid; i < cx.nthr / 64 * P * Y.wstride; i += cx.nthr) lds[Y.wpart + i] = 0.0;
+        if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
+    }
+    BB_SYNC(cx);
+    BB_PASS(cx, tid) {
+        // row j of the tile's moment row = sum over the virtual waves [vbeg, vend) of wpart[v][off]
+        int* rm = (int*)(lds + Y.rowmap);
+        const int nseg = li[0];
+        for (int j = tid; j < M.K; j += cx.nthr) {
+            int code = 0;
+            for (int si = 0; si < nseg; ++si) {
+                const BRSeg s = sg[si];
+                if (s.kind != SK_L) continue;
+                const int r = s.r, T = s.T, q0 = j - M.kq[r];
+                if (q0 < 0 || q0 >= 6 * T - 5) continue;
+                int tt, q;
+                if (q0 < T) { tt = q0; q = 0; } else { tt = (q0 - T) / 5; q = 1 + (q0 - T) - 5 * tt; }
+                const int off = (tt >> 1) * BR_NCV + (tt & 1) * 6 + q;
+                code = (s.tbeg >> 6) | (((s.tbeg + s.span + 63) >> 6) << 10) | (off << 20);
+            }
+            rm[j] = code;
+        }
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+        const int E = KIND == 1 ? M.E : 1;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int p = tid + k * cx.nthr;
+            int si = -1;
+            for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
+            int meta = 0;
+            long long i0 = 0;
+            st.zoff[k] = 0; st.uo[k][0] = st.uo[k][1] = st.uo[k][2] = 0; st.pt[k] = 0; st.cnt[k][0] = st.cnt[k][1] = 0u;
+            if (si >= 0) {
+                const BRSeg s = sg[si];
+                meta = s.kind | (si << 12);
+                if (s.kind == SK_L) {
+                    const int q = p - s.tbeg, bl = q / s.lpb, kk = q - bl * s.lpb;
+                    if (2 * kk < s.T) {
+                        const int t0 = 2 * kk;
+                        i0 = s.lo + (long long)bl * s.T + t0;
+                        meta |= BRM_A0 | BRM_A1 | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);
+                        st.zoff[k] = s.ldsoff + bl * s.T + t0;
+                        st.pt[k] = M.tcum[s.r] + t0;
+                        if (bl >= t.nshift) {
+                            meta |= BRM_MUT;
+                            const int ml = bl - t.nshift;
+                            for (int d = 0; d < 3; ++d) {     // differences t0-1, t0, t0+1 use the unit of time step (t0 - 1 + d)
+                                const int tt = t0 - 1 + d;
+                                const int e = (KIND == 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
+                                st.uo[k][d] = ml * E + e;
+                            }
+                        }
+                        const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
+                        st.cnt[k][0] = M.counts[cb];
+                        st.cnt[k][1] = M.counts[cb + 1];
+                    }
+                } else {
+                    const int q = p - s.tbeg;
+                    i0 = 2 * ((s.lo >> 1) + q);
+                    const bool a0 = i0 >= s.lo, a1 = i0 + 1 < s.hi;
+                    meta |= (a0 ? BRM_A0 : 0) | (a1 ? BRM_A1 : 0) | BRM_VALID;
+                    st.zoff[k] = (int)(i0 - s.lo);        // (may be -1 for a pair that starts one latent before the segment)
+                    if (s.kind == SK_S || s.kind == SK_LS_E) {
+                        // unit (ml, e) of latent x: index j = zoff + x = ml * E + e; its barcode's z row inside a zl buffer
+                        int env = 0;
+                        for (int x = 0; x < 2; ++x) {
+                            int j = st.zoff[k] + x;
+                            if (j < 0) j = 0;
+                            const int ml = j / E, e = j - ml * E;
+                            st.uo[k][x] = (t.nshift + ml) * M.T[0];
+                            env |= e << (8 * x);
+                        }
+                        st.uo[k][2] = env;
+                    }
+                }
+            }
+            st.i0[k] = i0;
+            st.meta[k] = meta;
+            st.wl[k] = 0;
+            for (int i = 0; i < nseg; ++i)
+                if (sg[i].kind == SK_L && (p & ~63) >= sg[i].tbeg && (p & ~63) < sg[i].tbeg + sg[i].span) st.wl[k] = sg[i].lpb;
+            const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+            st.mu[k] = bb_load_pair(S.mu, i0, a0, a1);
+            st.om[k] = bb_load_pair(S.om, i0, a0, a1);
+            st.am[k] = bb_load_pair(S.acc_mu, i0, a0, a1);
+            st.ao[k] = bb_load_pair(S.acc_om, i0, a0, a1);
+            st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
+            st.ap[k] = st.amid[k] = st.an[k] = st.wp[k] = st.wm[k] = st.wn[k] = 0.0;
+            for (int q = 0; q < BR_NCV; ++q) st.cv[k][q] = 0.0;
+        }
+    }
+    BB_SYNC(cx);
+}
+
+// ---- next step's standard normals (out of line on the GPU, as in bb_persist.h) -----------------------------------
+template <int P> struct BRIdx { long long i0[P]; int meta[P]; };
+
+template <int P>
+#ifdef BB_EMU
+static inline
+#else
+__device__ __attribute__((noinline))
+#endif
+void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsigned step, BRIdx<P> ix) {
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        if (!(ix.meta[k] & BRM_VALID)) continue;
+        double e0, e1;
+        bb_normal_pair(seed, (unsigned long long)(ix.i0[k] >> 1), step, 0u, &e0, &e1);
+        eps[k * nthr + tid] = bb_d2{e0, e1};              // read back by the same thread: no barrier needed
+    }
+}
+
+template <int P>
+BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+    bb_d2* eps = (bb_d2*)(cx.lds + Y.eps);
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+        BRIdx<P> ix;
+#pragma unroll
+        for (int k = 0; k < P; ++k) { ix.i0[k] = st.i0[k]; ix.meta[k] = st.meta[k]; }
+        br_draw_call<P>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
+    }
+}
+
+// ---- S: draw, stage ---------------------------------------------------------------------------------------------------
+template <int KIND, int P>
+BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf) {
+    double* lds = cx.lds;
+    const BBLds& L = Y.L;
+    BB_STAMP(cx, S, 20);
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if (!(meta & BRM_VALID)) continue;
+            const int kind = meta & 15;
+            const bb_d2 e = ((const bb_d2*)(lds + Y.eps))[k * cx.nthr + tid];
+            double sp0, sg0, sp1, sg1;
+            bb_softplus_sigmoid(st.om[k].x, &sp0, &sg0);
+            const double z0 = fma(sp0, e.x, st.mu[k].x);
+            st.a[k].x = e.x * sg0;
+            st.h[k].x = sg0 * bb_rcp(sp0);
+            BR_SCHED_FENCE();
+            bb_softplus_sigmoid(st.om[k].y, &sp1, &sg1);
+            const double z1 = fma(sp1, e.y, st.mu[k].y);
+            st.a[k].y = e.y * sg1;
+            st.h[k].y = sg1 * bb_rcp(sp1);
+            BR_SCHED_FENCE();
+            st.z[k] = bb_d2{z0, z1};
+            if (kind == SK_L) {
+                *(bb_d2*)(lds + Y.zl + buf * Y.NBT + st.zoff[k]) = bb_d2{z0, z1};      // zoff is even: T even, aligned segments
+                st.lam[k].x = bb_exp(z0);
+                BR_SCHED_FENCE();
+                st.lam[k].y = bb_exp(z1);
+            } else if (kind == SK_S) {
+                double* dst = lds + Y.st[0] + buf * Y.SU + st.zoff[k];
+                if (meta & BRM_A0) dst[0] = z0;
+                if (meta & BRM_A1) dst[1] = z1;
+            } else if (kind == SK_LS_E) {
+                double* dst = lds + Y.st[1] + buf * Y.SU + st.zoff[k];
+                const double w0 = bb_exp(-2.0 * z0), w1 = bb_exp(-2.0 * z1);
+                st.lam[k] = bb_d2{w0, w1};
+                if (meta & BRM_A0) dst[0] = w0;
+                if (meta & BRM_A1) dst[1] = w1;
+            } else {      // replicated global latents (tile 0 only): they ride along in the tile's row, every other tile adds +0.0
+                double* dst = lds + L.wk + M.K + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
+                if (A.count_globals) {     // (sharded run: rank 0's draw is THE draw)
+                    if (meta & BRM_A0) dst[0] = z0;
+                    if (meta & BRM_A1) dst[1] = z1;
+                }
+            }
+        }
+    }
+    BB_SYNC(cx);                     // barrier 1: neighbours' z and the unit stages are visible
+    BB_STAMP(cx, S, 21);
+}
+
+// ---- M: the pair's differences and moment contributions; wave sums -> LDS --------------------------------------------
+template <int KIND, int P>
+BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf) {
+    double* lds = cx.lds;
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            double* cv = st.cv[k];
+#pragma unroll
+            for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
+            if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
+            const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
+            const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+            const double z0 = st.z[k].x, z1 = st.z[k].y;
+            const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
+            double dp = z0 - zp, dm = z1 - z0, dn = zn - z1;
+            cv[0] = st.lam[k].x;
+            cv[6] = st.lam[k].y;
+            if (mut) {
+                const double* ts = lds + Y.st[0] + buf * Y.SU;
+                const double* tw = lds + Y.st[1] + buf * Y.SU;
+                double wp, wm, wn;
+                if (KIND == 1) {
+                    dp -= ts[st.uo[k][0]]; dm -= ts[st.uo[k][1]]; dn -= ts[st.uo[k][2]];
+                    wp = tw[st.uo[k][0]]; wm = tw[st.uo[k][1]]; wn = tw[st.uo[k][2]];
+                } else {
+                    const double s = ts[st.uo[k][1]];
+                    wp = wm = wn = tw[st.uo[k][1]];
+                    dp -= s; dm -= s; dn -= s;
+                }
+                st.wp[k] = wp; st.wm[k] = wm; st.wn[k] = wn;
+                cv[1] = wm; cv[2] = wm * dm; cv[3] = wm * dm * dm;
+                if (hn) { cv[7] = wn; cv[8] = wn * dn; cv[9] = wn * dn * dn; }
+            } else {
+                cv[4] = dm; cv[5] = dm * dm;
+                if (hn) { cv[10] = dn; cv[11] = dn * dn; }
+            }
+            st.ap[k] = dp; st.amid[k] = dm; st.an[k] = dn;
+        }
+    }
+    // wave sums: lanes with equal (lane % LPB) feed the same rows
+#ifdef BB_EMU
+    for (int k = 0; k < P; ++k)
+        for (int w = 0; w < cx.nthr / 64; ++w) {
+            const int lpb = stv[w * 64].wl[k];
+            if (!lpb) continue;
+            for (int kk = 0; kk < lpb; ++kk)
+                for (int q = 0; q < BR_NCV; ++q) {
+                    double s = 0.0;
+                    for (int lane = kk; lane < 64; lane += lpb) s += stv[w * 64 + lane].cv[k][q];
+                    lds[Y.wpart + (k * (cx.nthr / 64) + w) * Y.wstride + kk * BR_NCV + q] = s;
+                }
+        }
+#else
+    {
+        BRSt<P>& st = stv[0];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int lpb = __builtin_amdgcn_readfirstlane(st.wl[k]);
+            if (!lpb) continue;
+            double* cv = st.cv[k];
+            for (int m = lpb; m < 64; m <<= 1) {
+#pragma unroll
+                for (int q = 0; q < BR_NCV; ++q) cv[q] += __shfl_xor(cv[q], m, 64);
+            }
+            if (lane < lpb) {
+                double* dst = lds + Y.wpart + (k * (cx.nthr / 64) + wave) * Y.wstride + lane * BR_NCV;
+#pragma unroll
+                for (int q = 0; q < BR_NCV; ++q) dst[q] = cv[q];
+            }
+        }
+    }
+#endif
+    BB_SYNC(cx);                     // barrier 2: the waves' partial sums are in LDS
+    BB_STAMP(cx, S, 23);
+}
+
+// ---- the tile's row: K fixed-order sums over the waves + the riding global samples, published write-through ----------
+BB_DEV void br_publish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, unsigned epoch) {
+    const int KK = M.K + 2 * M.nt1;
+    double* lds = cx.lds;
+    const int* rm = (const int*)(lds + Y.rowmap);
+    BB_PASS(cx, tid) {
+        for (int j = tid; j < KK; j += cx.nthr) {
+            double s;
+            if (j < M.K) {
+                const int code = rm[j], vb = code & 1023, ve = (code >> 10) & 1023, off = code >> 20;
+                s = 0.0;
+                for (int v = vb; v < ve; ++v) s += lds[Y.wpart + v * Y.wstride + off];
+            } else s = lds[Y.L.wk + j];
+            bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
+        }
+    }
+    if (KK <= 64) {
+        // one wave stored the whole row: its own drain orders the ready word behind the row, no workgroup barrier
+#ifndef BB_EMU
+        if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    } else {
+        bb_drain_and_meet(cx);
+    }
+    BB_STAMP(cx, S, 24);
+    BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
+}
+
+// ---- window-slot prefetch (in the exchange's shadow) ----------------------------------------------------------------------
+template <int P>
+BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, BRSt<P>* stv, unsigned long long step) {
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+        if (A.opt == 0) {
+            const int slot = bb_slot_of(A, step).slot;
+            const double* hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dp;
+            const double* hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const bool a0 = st.meta[k] & BRM_A0, a1 = st.meta[k] & BRM_A1;
+                st.hm[k] = bb_load_pair(hs_m, st.i0[k], a0, a1);
+                st.ho[k] = bb_load_pair(hs_o, st.i0[k], a0, a1);
+            }
+        }
+    }
+}
+
+// ---- F: everything that depends only on the totals (tiny; ends with barrier 3) --------------------------------------------
+template <int KIND>
+BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y) {
+    double* lds = cx.lds;
+    const BBLds& L = Y.L;
+    BB_STAMP(cx, S, 25);
+    BB_PASS(cx, tid) {
+        for (int j = tid; j < M.Ttot; j += cx.nthr) {
+            int r = 0;
+            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
+            const int tt = j - M.tcum[r], T = M.T[r];
+            double Dt = 0.0, c = 0.0, wb = 0.0;
+            if (tt < T - 1) {
+                const double nn = (double)M.nn;
+                const double* mm = lds + L.wk + M.kq[r] + T + 5 * tt;
+                const double M0 = mm[0], M1 = mm[1], N1 = mm[3], N2 = mm[4];
+                const double sbar = lds[L.zgl + M.off_t[r] + tt], ls = lds[L.zgl + M.nt1 + M.off_t[r] + tt];
+                wb = bb_exp(-2.0 * ls);
+                c = lds[L.Lt + j + 1] - lds[L.Lt + j] - sbar;
+                const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
+                Dt = (M1 - c * M0) + wb * (N1 - c * nn);
+                lds[L.gglob + M.off_t[r] + tt] = -Dt;
+                lds[L.gglob + M.nt1 + M.off_t[r] + tt] = wb * quadN - nn;
+            }
+            lds[L.cc + j] = c;
+            lds[L.wbar + j] = wb;
+            lds[L.Dt + j] = Dt;
+            // G_t / S_t with G_t = D_{t-1} - D_t (D == 0 at t == T-1 and before t == 0).  Ttot <= 64 <= nthr: all of this is wave 0,
+            // whose LDS operations complete in order (D_{t-1} was stored by lane j-1 in the instruction above); the emulation runs
+            // the threads in index order
+            lds[Y.iG + j] = ((tt > 0 ? lds[L.Dt + j - 1] : 0.0) - Dt) * lds[L.invS + j];
+        }
+    }
+    BB_SYNC(cx);                     // barrier 3
+    BB_STAMP(cx, S, 26);
+}
+
+// ---- G: gradients from registers, prior, optimiser, window slot -----------------------------------------------------------
+template <int KIND, int P>
+BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
+                      unsigned long long step, int buf) {
+    double* lds = cx.lds;
+    const BBLds& L = Y.L;
+    const BBSlot wslot = bb_slot_of(A, step);
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+        double* hs_m = nullptr;
+        double* hs_o = nullptr;
+        if (A.opt == 0) {
+            hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dp;
+            hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
+        }
+        const int E = KIND == 1 ? M.E : 1;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if (!(meta & BRM_VALID)) continue;
+            const int kind = meta & 15;
+            const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+            const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
+            const int blk = sg[meta >> 12].blk;
+            const long long blo = M.blk_lo[blk];
+            double g0 = 0.0, g1 = 0.0;
+            if (kind == SK_L) {
+                const int pt = st.pt[k];
+                const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+                double wp = st.wp[k], wm = st.wm[k], wn = st.wn[k];
+                if (!mut) { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
+                const double rp = hp ? wp * (st.ap[k] - lds[L.cc + pt - 1]) : 0.0;
+                const double rm = wm * (st.amid[k] - lds[L.cc + pt]);
+                const double rn = hn ? wn * (st.an[k] - lds[L.cc + pt + 1]) : 0.0;
+                const double l0 = st.lam[k].x, l1 = st.lam[k].y;
+                g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm - rp;
+                g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn - rm;
+            } else if (kind == SK_S || kind == SK_LS_E) {
+                // per-unit sums over the time steps that use the unit:  As = w sum r,  Qs = w sum r^2 - n,  r = dl - s - c_t
+                const int T = M.T[0], T1 = T - 1;
+                const double* zbuf = lds + Y.zl + buf * Y.NBT;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    if (!(x ? a1 : a0)) continue;
+                    const int j = st.zoff[k] + x;
+                    const int e = (st.uo[k][2] >> (8 * x)) & 255;
+                    const double* zr = zbuf + st.uo[k][x];
+                    double s, w;
+                    if (kind == SK_S) { s = x ? st.z[k].y : st.z[k].x; w = lds[Y.st[1] + buf * Y.SU + j]; }
+                    else { w = x ? st.lam[k].y : st.lam[k].x; s = lds[Y.st[0] + buf * Y.SU + j]; }
+                    double As = 0.0, Qs = 0.0;
+                    int n = 0;
+                    for (int tt = 0; tt < T1; ++tt) {
+                        if (KIND == 1 && M.env_idx[tt + 1] != e) continue;
+                        const double rr = (zr[tt + 1] - zr[tt]) - s - lds[L.cc + tt];
+                        As += rr; Qs += rr * rr; ++n;
+                    }
+                    const double g = kind == SK_S ? w * As : w * Qs - (double)n;
+                    if (x) g1 = g; else g0 = g;
+                }
+                (void)E;
+            } else {
+                const double* gg = lds + L.gglob + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
+                if (a0) g0 = gg[0];
+                if (a1) g1 = gg[1];
+            }
+            // the replicated global latents' sample came back with the totals (rank 0's draw); everybody else kept its own
+            double z0 = st.z[k].x, z1 = st.z[k].y;
+            if (kind >= SK_GS) {
+                const double* zz = lds + L.zgl + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
+                if (a0) z0 = zz[0];
+                if (a1) z1 = zz[1];
+            }
+            double pm, iv;
+            if (a0) { bb_prior_of(M, blk, st.i0[k] - blo, &pm, &iv); g0 -= (z0 - pm) * iv; }
+            if (a1) { bb_prior_of(M, blk, st.i0[k] + 1 - blo, &pm, &iv); g1 -= (z1 - pm) * iv; }
+            const double go0 = fma(g0, st.a[k].x, st.h[k].x), go1 = fma(g1, st.a[k].y, st.h[k].y);
+            const bb_d2 hm = hs_m ? st.hm[k] : bb_d2{0, 0}, ho = hs_m ? st.ho[k] : bb_d2{0, 0};
+            bb_d2 nhm = hm, nho = ho;
+            if (a0) {
+                bb_opt_apply(M, S, A, wslot, 0, st.i0[k], -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x);
+                BR_SCHED_FENCE();
+                bb_opt_apply(M, S, A, wslot, 1, st.i0[k], -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x);
+                BR_SCHED_FENCE();
+            }
+            if (a1) {
+                bb_opt_apply(M, S, A, wslot, 0, st.i0[k] + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y);
+                BR_SCHED_FENCE();
+                bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y);
+                BR_SCHED_FENCE();
+            }
+            if (hs_m) { bb_store_pair(hs_m, st.i0[k], a0, a1, nhm); bb_store_pair(hs_o, st.i0[k], a0, a1, nho); }
+        }
+    }
+    BB_STAMP(cx, S, 28);
+}
+
+// ---- epilogue: state back to memory, step counter, status words ----------------------------------------------------------
+template <int P>
+BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned long long step_end, bool timed_out) {
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if (!(meta & BRM_VALID)) continue;
+            const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+            bb_store_pair(S.mu, st.i0[k], a0, a1, st.mu[k]);
+            bb_store_pair(S.om, st.i0[k], a0, a1, st.om[k]);
+            bb_store_pair(S.acc_mu, st.i0[k], a0, a1, st.am[k]);
+            bb_store_pair(S.acc_om, st.i0[k], a0, a1, st.ao[k]);
+            const double chk = (a0 ? st.mu[k].x + st.om[k].x : 0.0) + (a1 ? st.mu[k].y + st.om[k].y : 0.0);
+            bad = bad || !(chk - chk == 0.0);
+        }
+        if (bad) S.hstatus[1] = 1u;
+        if (timed_out && tid == 0) S.hstatus[0] = 1u;
+        if (cx.block == 0 && tid == 0) { S.ctr[0] = step_end; S.ctr[1] = step_end; }
+    }
+    BB_SYNC(cx);
+}
+
+// a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
+template <int P>
+BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+    br_publish(cx, M, S, Y, A.xepoch0 + (unsigned)(step + 1));
+    br_draw_ahead<P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
+}
+template <bool XG>
+BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, unsigned long long step, int* ok_slot) {
+    const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
+    if (cx.block < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+}
+template <int KIND, int P, bool XG>
+BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
+                            unsigned long long step, int* ok_slot) {
+    const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
+    br_prefetch_slot<P>(cx, M, S, A, stv, step);           // cold window lines fly while the rows arrive
+    bbp_consume<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+    br_finish<KIND>(cx, M, S, Y);
+}
+
+#ifndef BB_EMU
+template <int KIND, int P, int NT, bool XG = false>
+__global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, const BRLay* __restrict__ Yp,
+                                            RunArgs A, int NB, int nsteps) {
+    const DevModel& M = *Mp;
+    const DevState& S = *Sp;
+    const BRLay& Y = *Yp;
+    extern __shared__ __attribute__((aligned(16))) double br_smem[];
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, br_smem, nullptr};
+    BRSt<P> st;
+    int* ok_slot = (int*)(br_smem + Yp->L.misc) + 1;
+    const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
+    const unsigned long long step0 = c0 > c1 ? c0 : c1;
+    br_prologue<KIND, P>(cx, M, S, A, Y, NB, &st);
+    const bool dead = *ok_slot == 0;
+    int done = 0;
+    if (!dead) {
+        br_draw_ahead<P>(cx, A, Y, &st, step0);
+        for (; done < nsteps; ++done) {
+            const unsigned long long step = step0 + (unsigned long long)done;
+            const int buf = (int)(step & 1);
+            br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
+            br_moments<KIND, P>(cx, M, S, Y, &st, buf);
+            br_xchg_publish<P>(cx, M, S, A, Y, &st, step);
+            br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
+            br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
+            if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
+            br_update<KIND, P>(cx, M, S, A, Y, &st, step, buf);
+        }
+    }
+    br_epilogue<P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
+}
+#endif

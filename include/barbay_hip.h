@@ -137,6 +137,8 @@ typedef struct bb_stats {
     int32_t n_blocks, block_threads, lds_bytes;
     int32_t persistent_pairs;  /* > 0: bb_run uses the resident launch with this many latent pairs per thread */
     int32_t launches_last_run; /* kernel launches of the last bb_run (resident launch: <= 4096 steps each)       */
+    int32_t resident_kernel;   /* which resident launch bb_run uses: 0 none (two kernels per sample), 1 k_persist
+                                  (LDS-staged passes), 2 k_res (the owner of a latent computes; bb_resident.h)     */
 } bb_stats;
 
 const char* bb_version(void);

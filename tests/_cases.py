@@ -17,6 +17,10 @@ SYNTH = {
     "fitness_multi_tile": ("fitness", dict(B=700, T=5, n_neutral=37)),
     "fitness_neutral_heavy": ("fitness", dict(B=513, T=8, n_neutral=300)),
     "fitness_T2": ("fitness", dict(B=130, T=2, n_neutral=3)),
+    "fitness_T6": ("fitness", dict(B=700, T=6, n_neutral=37)),          # even T: the owner-computes resident launch (k_res), LPB 4 with an idle lane
+    "fitness_T4": ("fitness", dict(B=333, T=4, n_neutral=70)),
+    "multienv_T6": ("multienv", dict(B=600, T=6, n_env=3, n_neutral=11)),
+    "multienv_T8": ("multienv", dict(B=300, T=8, n_env=4, n_neutral=40)),
     "multienv": ("multienv", dict(B=600, T=7, n_env=3, n_neutral=11)),
     "genotype": ("genotype", dict(B=800, T=6, n_geno=17, n_neutral=256)),
     "replicate_ragged": ("replicate", dict(B=530, T=[5, 7, 4], n_rep=3, n_neutral=20)),
@@ -175,7 +179,7 @@ def case_errors(lib):
         bb.Engine("fitness", sp.counts, sp.n_neutral, sp.n_bc, samples_per_step=0, _lib=lib)
 
 
-def case_persistent_equals_two_kernel(lib, name, tol=1e-11, **geom):
+def case_persistent_equals_two_kernel(lib, name, tol=1e-11, expect_kernel=None, **geom):
     """launch_mode 2 (one resident launch, state in registers, grid barrier per step) and launch_mode 1
     (two kernels per sample) run the same arithmetic; also against the oracle with the exact window."""
     sp = synth(name, seed=6)
@@ -189,6 +193,8 @@ def case_persistent_equals_two_kernel(lib, name, tol=1e-11, **geom):
             e.run(10)
             outs.append(e.get_params())
             assert e.stats()["steps_done"] == 17
+            if mode == 2 and expect_kernel is not None:
+                assert e.stats()["resident_kernel"] == expect_kernel, e.stats()
     assert np.abs(outs[0][0] - outs[1][0]).max() < tol and np.abs(outs[0][1] - outs[1][1]).max() < tol
     e, a, b, _ = _trajectory(lib, sp, 9, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
     e.close()

@@ -62,6 +62,21 @@ def test_persistent_equals_two_kernel(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name)
 
 
+@pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8"])
+def test_owner_computes_launch_equals_two_kernel(emu_lib, name):
+    """Even T: launch_mode 2 is k_res (bb_resident.h); same arithmetic as the two-kernel step and the oracle."""
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
+
+
+@pytest.mark.parametrize("nb,nthr", [(100, 256), (24, 128), (150, 512), (40, 128), (9, 64)])
+def test_owner_computes_launch_geometries(emu_lib, monkeypatch, nb, nthr):
+    """several pair slots per thread, tiles that end inside a wave, neutral / mutant boundary inside a tile"""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    c.case_persistent_equals_two_kernel(emu_lib, "fitness_T6", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(emu_lib, "multienv_T8", expect_kernel=2)
+
+
 def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NB", "120")     # 120 barcodes x (16 + 1 + 9) latents / 2 > 1024 pairs -> P = 2
     monkeypatch.setenv("BB_TUNE_NTHR", "1024")
@@ -100,7 +115,7 @@ def test_logdensity_grad(emu_lib, name):
 
 
 @pytest.mark.parametrize("name,world", [("fitness_multi_tile", 2), ("fitness_multi_tile", 3), ("multienv", 2), ("replicate_ragged", 2),
-                                        ("multienv_replicate", 2)])
+                                        ("multienv_replicate", 2), ("fitness_T6", 2), ("fitness_T6", 3), ("multienv_T8", 2)])
 def test_sharded_resident_launch(emu_lib, monkeypatch, name, world):
     monkeypatch.setenv("BB_TUNE_NB", "16")         # >= 8 tiles on every rank, one pair per thread
     monkeypatch.setenv("BB_TUNE_NTHR", "512")

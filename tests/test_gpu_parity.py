@@ -201,3 +201,18 @@ def test_runs_are_bit_reproducible(hip_lib, mode):
             e.run(250)                       # past the first window re-adds
             outs.append(e.get_params())
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
+@pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8"])
+def test_owner_computes_launch_equals_two_kernel(hip_lib, name):
+    """Even T: launch_mode 2 is k_res (bb_resident.h, the owner of a latent computes); same arithmetic as the two-kernel
+    step and as the literal oracle's optimiser trajectory."""
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
+
+
+@pytest.mark.parametrize("nb,nthr", [(100, 256), (24, 128), (150, 512), (40, 128), (9, 64), (196, 1024)])
+def test_owner_computes_launch_geometries(hip_lib, monkeypatch, nb, nthr):
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    c.case_persistent_equals_two_kernel(hip_lib, "fitness_T6", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(hip_lib, "multienv_T8", expect_kernel=2)
