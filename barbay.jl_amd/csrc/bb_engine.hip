@@ -353,6 +353,10 @@ static int launch_check();
 #ifndef BB_EMU
 typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, int);
 static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false) {
+#ifdef BB_FAST_BUILD   /* experiment builds (tools/ab_persist.py): only the instances the C2 / C4 workloads use */
+    if (!xg && nthr > 512 && P == 1 && kind == 0) return k_persist<0, 1, 1024>;
+    return nullptr;
+#else
     if (xg) {                  // sharded tiles are small: one pair per thread only
         if (P != 1) return nullptr;
         if (nthr > 512) switch (kind) {
@@ -382,12 +386,19 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = fal
     case 41: return k_persist<4, 1, 512>;  case 42: return k_persist<4, 2, 512>;  case 43: return k_persist<4, 3, 512>;  case 44: return k_persist<4, 4, 512>;
     default: return nullptr;
     }
+#endif
 }
 #endif
 
 #ifndef BB_EMU
 typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
 static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg) {
+#ifdef BB_FAST_BUILD
+    if (xg) return nullptr;
+    if (nthr > 512 && P == 1) return kind == 0 ? k_res<0, 1, 1024, false> : (kind == 1 ? k_res<1, 1, 1024, false> : nullptr);
+    if (nthr > 256 && nthr <= 512 && P == 2 && kind == 0) return k_res<0, 2, 512, false>;
+    return nullptr;
+#else
 #define BR_CASE(K, PP, NT) case (K) * 10 + (PP): return xg ? k_res<K, PP, NT, true> : k_res<K, PP, NT, false>;
     if (nthr > 512) {          // 16 waves per CU: 128 registers per lane
         switch (kind * 10 + P) { BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) default: return nullptr; }
@@ -404,6 +415,7 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg) {
         default: return nullptr;
     }
 #undef BR_CASE
+#endif
 }
 #endif
 
@@ -581,7 +593,7 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             br_draw_ahead<PP>(cx, A, Y, sb, (unsigned long long)h->step);
         } else if (phase == 1) {
             br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
-            br_moments<KIND, PP>(cx, h->M, h->S, Y, sb, buf);
+            br_moments<KIND, PP>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_publish<PP>(cx, h->M, h->S, A, Y, sb, step);
         } else if (phase == 2) {
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);

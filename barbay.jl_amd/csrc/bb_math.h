@@ -21,6 +21,27 @@
 #define BB_RSQ_SEED(x) (1.0 / sqrt(x))
 #endif
 
+// BB_FMAK(a, b, k) = a * b + k for a compile-time constant k.  On the device the constant is moved into a FIXED scalar register
+// pair right in front of the v_fma_f64 that reads it (one asm block, s[92:93] clobbered).  Left to hipcc a Horner step becomes
+// the two-address v_fmac_f64 whose accumulator is a VGPR pair initialised with the constant (two VALU moves per coefficient),
+// and the ~60 coefficients of a sampling pass are either hoisted out of the resident launch's step loop (dozens of VGPRs alive
+// for the whole launch) or, as register-allocated scalars, push ~60 live scalars of the kernel into VGPR lanes and back
+// (v_writelane / v_readlane) every step.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BB_NO_ASM_FMA)
+#define BB_FMAK(a, b, k)                                                                                                   \
+    ({                                                                                                                     \
+        double bb_r_;                                                                                                      \
+        asm("s_mov_b32 s92, %3\n\ts_mov_b32 s93, %4\n\tv_fma_f64 %0, %1, %2, s[92:93]"                                  \
+            : "=v"(bb_r_)                                                                                                  \
+            : "v"((double)(a)), "v"((double)(b)), "i"((int)(__builtin_bit_cast(unsigned long long, (double)(k)) & 0xffffffffull)), \
+              "i"((int)(__builtin_bit_cast(unsigned long long, (double)(k)) >> 32))                                        \
+            : "s92", "s93");                                                                                             \
+        bb_r_;                                                                                                             \
+    })
+#else
+#define BB_FMAK(a, b, k) fma((double)(a), (double)(b), (double)(k))
+#endif
+
 // 1/x for finite, non-zero, normal x: seed + 2 Newton steps.
 BB_DEV double bb_rcp(double x) {
     double r = BB_RCP_SEED(x);
@@ -57,19 +78,19 @@ BB_DEV double bb_exp(double x) {
     double r = fma(-k, 6.93147180369123816490e-01, x);
     r = fma(-k, 1.90821492927058770002e-10, r);
     double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    p = BB_FMAK(p, r, 1.0 / 479001600.0);
+    p = BB_FMAK(p, r, 1.0 / 39916800.0);
+    p = BB_FMAK(p, r, 1.0 / 3628800.0);
+    p = BB_FMAK(p, r, 1.0 / 362880.0);
+    p = BB_FMAK(p, r, 1.0 / 40320.0);
+    p = BB_FMAK(p, r, 1.0 / 5040.0);
+    p = BB_FMAK(p, r, 1.0 / 720.0);
+    p = BB_FMAK(p, r, 1.0 / 120.0);
+    p = BB_FMAK(p, r, 1.0 / 24.0);
+    p = BB_FMAK(p, r, 1.0 / 6.0);
+    p = BB_FMAK(p, r, 0.5);
+    p = BB_FMAK(p, r, 1.0);
+    p = BB_FMAK(p, r, 1.0);
     return ldexp(p, (int)k);
 }
 
@@ -81,17 +102,17 @@ BB_DEV double bb_log(double x) {
     const double s = bb_div(m - 1.0, m + 1.0);
     const double z = s * s;
     double p = 1.0 / 25.0;
-    p = fma(p, z, 1.0 / 23.0);
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
+    p = BB_FMAK(p, z, 1.0 / 23.0);
+    p = BB_FMAK(p, z, 1.0 / 21.0);
+    p = BB_FMAK(p, z, 1.0 / 19.0);
+    p = BB_FMAK(p, z, 1.0 / 17.0);
+    p = BB_FMAK(p, z, 1.0 / 15.0);
+    p = BB_FMAK(p, z, 1.0 / 13.0);
+    p = BB_FMAK(p, z, 1.0 / 11.0);
+    p = BB_FMAK(p, z, 1.0 / 9.0);
+    p = BB_FMAK(p, z, 1.0 / 7.0);
+    p = BB_FMAK(p, z, 1.0 / 5.0);
+    p = BB_FMAK(p, z, 1.0 / 3.0);
     const double lm = fma(2.0 * s * z, p, 2.0 * s);     // 2s + 2s z P(z)
     const double ef = (double)e;
     return fma(ef, 6.93147180369123816490e-01, fma(ef, 1.90821492927058770002e-10, lm));
@@ -114,21 +135,21 @@ BB_DEV void bb_sincospi_02(double x, double* s, double* c) {
     const double y = fma(-0.5, n, x) * 3.14159265358979323846;
     const double z = y * y;
     double ps = -1.0 / 1307674368000.0;            // -1/15!
-    ps = fma(ps, z, 1.0 / 6227020800.0);           //  1/13!
-    ps = fma(ps, z, -1.0 / 39916800.0);
-    ps = fma(ps, z, 1.0 / 362880.0);
-    ps = fma(ps, z, -1.0 / 5040.0);
-    ps = fma(ps, z, 1.0 / 120.0);
-    ps = fma(ps, z, -1.0 / 6.0);
+    ps = BB_FMAK(ps, z, 1.0 / 6227020800.0);           //  1/13!
+    ps = BB_FMAK(ps, z, -1.0 / 39916800.0);
+    ps = BB_FMAK(ps, z, 1.0 / 362880.0);
+    ps = BB_FMAK(ps, z, -1.0 / 5040.0);
+    ps = BB_FMAK(ps, z, 1.0 / 120.0);
+    ps = BB_FMAK(ps, z, -1.0 / 6.0);
     const double sy = fma(y * z, ps, y);
     double pc = 1.0 / 20922789888000.0;            //  1/16!
-    pc = fma(pc, z, -1.0 / 87178291200.0);         // -1/14!
-    pc = fma(pc, z, 1.0 / 479001600.0);
-    pc = fma(pc, z, -1.0 / 3628800.0);
-    pc = fma(pc, z, 1.0 / 40320.0);
-    pc = fma(pc, z, -1.0 / 720.0);
-    pc = fma(pc, z, 1.0 / 24.0);
-    pc = fma(pc, z, -0.5);
+    pc = BB_FMAK(pc, z, -1.0 / 87178291200.0);         // -1/14!
+    pc = BB_FMAK(pc, z, 1.0 / 479001600.0);
+    pc = BB_FMAK(pc, z, -1.0 / 3628800.0);
+    pc = BB_FMAK(pc, z, 1.0 / 40320.0);
+    pc = BB_FMAK(pc, z, -1.0 / 720.0);
+    pc = BB_FMAK(pc, z, 1.0 / 24.0);
+    pc = BB_FMAK(pc, z, -0.5);
     const double cy = fma(z, pc, 1.0);
     const int q = (int)n & 3;
     const double ss = (q & 1) ? cy : sy, cc = (q & 1) ? sy : cy;

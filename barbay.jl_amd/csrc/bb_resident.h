@@ -36,7 +36,7 @@
 // Scheduling fence: the two latents of a pair run the same long fp64 chains (softplus / sigmoid / exp / sqrt / rcp); interleaved for
 // ILP they double the live temporaries and the 128-VGPR budget of a 16-wave workgroup spills.  Four waves per SIMD hide the
 // dependent-issue latency anyway, so the chains are kept one after the other.
-#if defined(BB_EMU)
+#if defined(BB_EMU) || defined(BR_NO_FENCE)
 #define BR_SCHED_FENCE() ((void)0)
 #else
 #define BR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -51,8 +51,9 @@ struct BRLay {
     int st[4], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w
                          //                                  hierarchical        0 = theta_tilde, 1 = e^logtau, 2 = w, 3 = theta
     int eps;             // [P * NT] bb_d2: the next step's normals
-    int wpart, wstride;  // [V][wstride] wave partial sums, wstride = 12 * max LPB
-    int rowmap;          // [K] ints: vbeg | vend << 10 | off << 20
+    int racc, rstride, rwidth;   // [12][rstride] the moment contributions of threads 0 .. rwidth-1 (the loglambda lanes), transposed;
+                         // rstride = rwidth + 4: the 12 columns start in different banks
+    int rowmap;          // [K] ints: time-pair class k | value index v << 8 | used << 16
     int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
     int seg;             // BRSeg table
     int total;
@@ -102,8 +103,11 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P) {
     for (int i = 0; i < 4; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
     o = (o + 1) & ~1;
     Y.eps = o;     o += 2 * P * NT;
-    Y.wstride = BR_NCV * lmax;
-    Y.wpart = o;   o += P * (NT / 64) * Y.wstride;
+    {   // lanes of the loglambda segment, rounded up to whole waves (unit lanes beyond them contribute nothing)
+        long long w = ((long long)NB * Y.lpb[0] + 63) & ~63ll;
+        Y.rwidth = (int)(w < NT ? w : NT);
+        Y.rstride = Y.rwidth + 4;
+    }
     Y.rowmap = o;  o += (M.K + 1) / 2 + 1;
     L.wk = o;      o += KK;
     L.zgl = o;     o += 2 * M.nt1;
@@ -122,8 +126,12 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P) {
     Y.seg = o;     o += 6 * (BB_MAX_SEG + 1);
     L.seg = Y.seg;
     o = (o + 1) & ~1;
-    L.acc = o;     o += (BB_NQ + 1) * NT;      // staging of the cross-GPU inbox rows (bbp_consume<true>)
+    // one transient region, two users that never overlap in time: the transposed moment contributions (M pass -> row sums) and the
+    // staging of the cross-GPU inbox rows (bbp_consume<true>)
+    Y.racc = L.acc = o;
+    o += BR_NCV * Y.rstride > (BB_NQ + 1) * NT ? BR_NCV * Y.rstride : (BB_NQ + 1) * NT;
     L.red = o;     o += KK + 16;
+    (void)lmax;
     L.total = Y.total = (o + 1) & ~1;
     return Y;
 }
@@ -137,7 +145,6 @@ struct BRSt {
     bb_d2 lam[P];                       // loglambda pairs: e^z
     double ap[P], amid[P], an[P];       // loglambda pairs: a = dl - s_eff of the backward / inner / forward difference
     double wp[P], wm[P], wn[P];         // ... and the mutant's precisions there
-    double cv[P][BR_NCV];               // moment contributions (alive between the M pass and the wave sum)
     long long i0[P];
     int meta[P];                        // seg kind | a0 << 4 | a1 << 5 | valid << 6 | mutant << 7 | has_prev << 8 | has_next << 9 | seg index << 12
     int zoff[P];                        // loglambda: offset of z0 inside one zl buffer; unit pairs: index of latent 0 inside its stage table
@@ -145,7 +152,6 @@ struct BRSt {
                                         // unit pairs: [0], [1] = zl-buffer offset of the barcode row of latent 0 / 1, [2] = env of latent 0 | env of latent 1 << 8
     int pt[P];                          // loglambda: tcum[r] + t0; unit pairs: tcum[r]
     unsigned cnt[P][2];                 // loglambda: the two counts
-    int wl[P];                          // LPB of the loglambda segment that covers this thread's WAVE in pair slot k (0: none) -- wave-uniform
 };
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
@@ -196,25 +202,20 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
         for (int i = tid; i < 2 * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
         for (int i = tid; i < 2 * Y.nst * Y.SU; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
-        for (int i = tid; i < cx.nthr / 64 * P * Y.wstride; i += cx.nthr) lds[Y.wpart + i] = 0.0;
         if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
-        // row j of the tile's moment row = sum over the virtual waves [vbeg, vend) of wpart[v][off]
+        // row j of the tile's moment row = sum over the threads of time-pair class k (tid % LPB == k) of their value v
         int* rm = (int*)(lds + Y.rowmap);
         const int nseg = li[0];
         for (int j = tid; j < M.K; j += cx.nthr) {
             int code = 0;
-            for (int si = 0; si < nseg; ++si) {
-                const BRSeg s = sg[si];
-                if (s.kind != SK_L) continue;
-                const int r = s.r, T = s.T, q0 = j - M.kq[r];
-                if (q0 < 0 || q0 >= 6 * T - 5) continue;
+            const int r = 0, T = M.T[0], q0 = j - M.kq[r];      // (one loglambda segment: fitness / multienv have no replicates)
+            if (q0 >= 0 && q0 < 6 * T - 5) {
                 int tt, q;
                 if (q0 < T) { tt = q0; q = 0; } else { tt = (q0 - T) / 5; q = 1 + (q0 - T) - 5 * tt; }
-                const int off = (tt >> 1) * BR_NCV + (tt & 1) * 6 + q;
-                code = (s.tbeg >> 6) | (((s.tbeg + s.span + 63) >> 6) << 10) | (off << 20);
+                code = (tt >> 1) | (((tt & 1) * 6 + q) << 8) | (1 << 16);
             }
             rm[j] = code;
         }
@@ -274,9 +275,6 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             }
             st.i0[k] = i0;
             st.meta[k] = meta;
-            st.wl[k] = 0;
-            for (int i = 0; i < nseg; ++i)
-                if (sg[i].kind == SK_L && (p & ~63) >= sg[i].tbeg && (p & ~63) < sg[i].tbeg + sg[i].span) st.wl[k] = sg[i].lpb;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
             st.mu[k] = bb_load_pair(S.mu, i0, a0, a1);
             st.om[k] = bb_load_pair(S.om, i0, a0, a1);
@@ -284,7 +282,6 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.ao[k] = bb_load_pair(S.acc_om, i0, a0, a1);
             st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
             st.ap[k] = st.amid[k] = st.an[k] = st.wp[k] = st.wm[k] = st.wn[k] = 0.0;
-            for (int q = 0; q < BR_NCV; ++q) st.cv[k][q] = 0.0;
         }
     }
     BB_SYNC(cx);
@@ -322,6 +319,8 @@ BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* 
 }
 
 // ---- S: draw, stage ---------------------------------------------------------------------------------------------------
+// The long fp64 chains (softplus / sigmoid, exp) run for ALL pair slots without a branch, so that the compiler may interleave
+// the slots' chains; only the stores depend on what the pair is.
 template <int KIND, int P>
 BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf) {
     double* lds = cx.lds;
@@ -331,42 +330,36 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const int meta = st.meta[k];
-            if (!(meta & BRM_VALID)) continue;
-            const int kind = meta & 15;
             const bb_d2 e = ((const bb_d2*)(lds + Y.eps))[k * cx.nthr + tid];
             double sp0, sg0, sp1, sg1;
             bb_softplus_sigmoid(st.om[k].x, &sp0, &sg0);
-            const double z0 = fma(sp0, e.x, st.mu[k].x);
-            st.a[k].x = e.x * sg0;
-            st.h[k].x = sg0 * bb_rcp(sp0);
-            BR_SCHED_FENCE();
             bb_softplus_sigmoid(st.om[k].y, &sp1, &sg1);
-            const double z1 = fma(sp1, e.y, st.mu[k].y);
-            st.a[k].y = e.y * sg1;
-            st.h[k].y = sg1 * bb_rcp(sp1);
+            st.z[k] = bb_d2{fma(sp0, e.x, st.mu[k].x), fma(sp1, e.y, st.mu[k].y)};
+            st.a[k] = bb_d2{e.x * sg0, e.y * sg1};
+            st.h[k] = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
             BR_SCHED_FENCE();
-            st.z[k] = bb_d2{z0, z1};
+            // loglambda: lambda = e^z; logsigma_bc: precision w = e^{-2 z}; (others: unused)
+            const double f = (st.meta[k] & 15) == SK_LS_E ? -2.0 : 1.0;
+            st.lam[k] = bb_d2{bb_exp(f * st.z[k].x), bb_exp(f * st.z[k].y)};
+            BR_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if (!(meta & BRM_VALID)) continue;
+            const int kind = meta & 15;
             if (kind == SK_L) {
-                *(bb_d2*)(lds + Y.zl + buf * Y.NBT + st.zoff[k]) = bb_d2{z0, z1};      // zoff is even: T even, aligned segments
-                st.lam[k].x = bb_exp(z0);
-                BR_SCHED_FENCE();
-                st.lam[k].y = bb_exp(z1);
-            } else if (kind == SK_S) {
-                double* dst = lds + Y.st[0] + buf * Y.SU + st.zoff[k];
-                if (meta & BRM_A0) dst[0] = z0;
-                if (meta & BRM_A1) dst[1] = z1;
-            } else if (kind == SK_LS_E) {
-                double* dst = lds + Y.st[1] + buf * Y.SU + st.zoff[k];
-                const double w0 = bb_exp(-2.0 * z0), w1 = bb_exp(-2.0 * z1);
-                st.lam[k] = bb_d2{w0, w1};
-                if (meta & BRM_A0) dst[0] = w0;
-                if (meta & BRM_A1) dst[1] = w1;
+                *(bb_d2*)(lds + Y.zl + buf * Y.NBT + st.zoff[k]) = st.z[k];      // zoff is even: T even, aligned segments
+            } else if (kind == SK_S || kind == SK_LS_E) {
+                double* dst = lds + Y.st[kind == SK_S ? 0 : 1] + buf * Y.SU + st.zoff[k];
+                const bb_d2 v = kind == SK_S ? st.z[k] : st.lam[k];
+                if (meta & BRM_A0) dst[0] = v.x;
+                if (meta & BRM_A1) dst[1] = v.y;
             } else {      // replicated global latents (tile 0 only): they ride along in the tile's row, every other tile adds +0.0
                 double* dst = lds + L.wk + M.K + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
                 if (A.count_globals) {     // (sharded run: rank 0's draw is THE draw)
-                    if (meta & BRM_A0) dst[0] = z0;
-                    if (meta & BRM_A1) dst[1] = z1;
+                    if (meta & BRM_A0) dst[0] = st.z[k].x;
+                    if (meta & BRM_A1) dst[1] = st.z[k].y;
                 }
             }
         }
@@ -375,26 +368,46 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     BB_STAMP(cx, S, 21);
 }
 
-// ---- M: the pair's differences and moment contributions; wave sums -> LDS --------------------------------------------
+// sum of s over the 16 lanes of a DPP row (every lane gets it)
+#ifndef BB_EMU
+template <int CTRL>
+__device__ __forceinline__ double br_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double br_row16_sum(double s) {
+    s += br_dpp<0x128>(s);   // row_ror:8
+    s += br_dpp<0x124>(s);   // row_ror:4
+    s += br_dpp<0x122>(s);   // row_ror:2
+    s += br_dpp<0x121>(s);   // row_ror:1
+    return s;
+}
+#endif
+
+// ---- M: the pairs' differences and moment contributions, summed in the thread over its pair slots (they share the time pair),
+// transposed into LDS; after the barrier 16 lanes per row entry walk their column and a DPP row sum finishes the entry, which
+// goes straight to the tile's published row ------------------------------------------------------------------------------------
 template <int KIND, int P>
-BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf) {
+BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch) {
     double* lds = cx.lds;
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
+        double cv[BR_NCV];
+#pragma unroll
+        for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int meta = st.meta[k];
-            double* cv = st.cv[k];
-#pragma unroll
-            for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
             if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
             const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
             const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
             const double z0 = st.z[k].x, z1 = st.z[k].y;
             const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
             double dp = z0 - zp, dm = z1 - z0, dn = zn - z1;
-            cv[0] = st.lam[k].x;
-            cv[6] = st.lam[k].y;
+            cv[0] += st.lam[k].x;
+            cv[6] += st.lam[k].y;
             if (mut) {
                 const double* ts = lds + Y.st[0] + buf * Y.SU;
                 const double* tw = lds + Y.st[1] + buf * Y.SU;
@@ -408,77 +421,41 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
                     dp -= s; dm -= s; dn -= s;
                 }
                 st.wp[k] = wp; st.wm[k] = wm; st.wn[k] = wn;
-                cv[1] = wm; cv[2] = wm * dm; cv[3] = wm * dm * dm;
-                if (hn) { cv[7] = wn; cv[8] = wn * dn; cv[9] = wn * dn * dn; }
+                cv[1] += wm; cv[2] += wm * dm; cv[3] += wm * dm * dm;
+                if (hn) { cv[7] += wn; cv[8] += wn * dn; cv[9] += wn * dn * dn; }
             } else {
-                cv[4] = dm; cv[5] = dm * dm;
-                if (hn) { cv[10] = dn; cv[11] = dn * dn; }
+                cv[4] += dm; cv[5] += dm * dm;
+                if (hn) { cv[10] += dn; cv[11] += dn * dn; }
             }
             st.ap[k] = dp; st.amid[k] = dm; st.an[k] = dn;
         }
-    }
-    // wave sums: lanes with equal (lane % LPB) feed the same rows
-#ifdef BB_EMU
-    for (int k = 0; k < P; ++k)
-        for (int w = 0; w < cx.nthr / 64; ++w) {
-            const int lpb = stv[w * 64].wl[k];
-            if (!lpb) continue;
-            for (int kk = 0; kk < lpb; ++kk)
-                for (int q = 0; q < BR_NCV; ++q) {
-                    double s = 0.0;
-                    for (int lane = kk; lane < 64; lane += lpb) s += stv[w * 64 + lane].cv[k][q];
-                    lds[Y.wpart + (k * (cx.nthr / 64) + w) * Y.wstride + kk * BR_NCV + q] = s;
-                }
-        }
-#else
-    {
-        BRSt<P>& st = stv[0];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (tid < Y.rwidth) {
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const int lpb = __builtin_amdgcn_readfirstlane(st.wl[k]);
-            if (!lpb) continue;
-            double* cv = st.cv[k];
-            for (int m = lpb; m < 64; m <<= 1) {
-#pragma unroll
-                for (int q = 0; q < BR_NCV; ++q) cv[q] += __shfl_xor(cv[q], m, 64);
-            }
-            if (lane < lpb) {
-                double* dst = lds + Y.wpart + (k * (cx.nthr / 64) + wave) * Y.wstride + lane * BR_NCV;
-#pragma unroll
-                for (int q = 0; q < BR_NCV; ++q) dst[q] = cv[q];
-            }
+            for (int q = 0; q < BR_NCV; ++q) lds[Y.racc + q * Y.rstride + tid] = cv[q];
         }
     }
-#endif
-    BB_SYNC(cx);                     // barrier 2: the waves' partial sums are in LDS
+    BB_SYNC(cx);                     // barrier 2: the contributions are in LDS
     BB_STAMP(cx, S, 23);
-}
-
-// ---- the tile's row: K fixed-order sums over the waves + the riding global samples, published write-through ----------
-BB_DEV void br_publish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, unsigned epoch) {
     const int KK = M.K + 2 * M.nt1;
-    double* lds = cx.lds;
     const int* rm = (const int*)(lds + Y.rowmap);
+    const int lpb = Y.lpb[0], nk = Y.rwidth / lpb;
     BB_PASS(cx, tid) {
-        for (int j = tid; j < KK; j += cx.nthr) {
-            double s;
-            if (j < M.K) {
-                const int code = rm[j], vb = code & 1023, ve = (code >> 10) & 1023, off = code >> 20;
-                s = 0.0;
-                for (int v = vb; v < ve; ++v) s += lds[Y.wpart + v * Y.wstride + off];
-            } else s = lds[Y.L.wk + j];
-            bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
-        }
-    }
-    if (KK <= 64) {
-        // one wave stored the whole row: its own drain orders the ready word behind the row, no workgroup barrier
-#ifndef BB_EMU
-        if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int c = tid & 15;
+        for (int j = tid >> 4; j < M.K; j += cx.nthr >> 4) {
+            const int code = rm[j], kc = code & 255, v = (code >> 8) & 255;
+            const double* col = lds + Y.racc + v * Y.rstride + kc;
+            double s = 0.0;
+#ifdef BB_EMU
+            if (c == 0 && (code >> 16)) for (int e = 0; e < nk; ++e) s += col[e * lpb];
+#else
+            if (code >> 16) for (int e = c; e < nk; e += 16) s += col[e * lpb];
+            s = br_row16_sum(s);
 #endif
-    } else {
-        bb_drain_and_meet(cx);
+            if (c == 0) bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
+        }
+        for (int j = M.K + tid; j < KK; j += cx.nthr) bb_st<true>(S.prow + (long long)cx.block * KK + j, lds[Y.L.wk + j]);
     }
+    bb_drain_and_meet(cx);           // every storing wave has drained its write-through stores
     BB_STAMP(cx, S, 24);
     BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
 }
@@ -664,7 +641,6 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
 template <int P>
 BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
-    br_publish(cx, M, S, Y, A.xepoch0 + (unsigned)(step + 1));
     br_draw_ahead<P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
 }
 template <bool XG>
@@ -703,7 +679,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
             const unsigned long long step = step0 + (unsigned long long)done;
             const int buf = (int)(step & 1);
             br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
-            br_moments<KIND, P>(cx, M, S, Y, &st, buf);
+            br_moments<KIND, P>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_publish<P>(cx, M, S, A, Y, &st, step);
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);

@@ -210,7 +210,7 @@ def test_owner_computes_launch_equals_two_kernel(hip_lib, name):
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
 
 
-@pytest.mark.parametrize("nb,nthr", [(100, 256), (24, 128), (150, 512), (40, 128), (9, 64), (196, 1024)])
+@pytest.mark.parametrize("nb,nthr", [(100, 256), (24, 128), (150, 512), (40, 128), (9, 64), (96, 1024)])
 def test_owner_computes_launch_geometries(hip_lib, monkeypatch, nb, nthr):
     monkeypatch.setenv("BB_TUNE_NB", str(nb))
     monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))

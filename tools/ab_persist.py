@@ -12,7 +12,7 @@ import __graft_entry__ as g  # noqa: E402
 AB = os.path.join(g.PKG, "lib", "ab")
 if len(sys.argv) > 2 and sys.argv[1] == "--build":
     os.makedirs(AB, exist_ok=True)
-    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,-Bsymbolic",
+    subprocess.run(["/opt/rocm/bin/hipcc", *g.HIP_FLAGS,
                     *sys.argv[3:], g.SRC, "-o", os.path.join(AB, sys.argv[2] + ".so"), "-ldl"], check=True)
     sys.exit(0)
 import barbay_jl_amd as bb  # noqa: E402

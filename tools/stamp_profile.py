@@ -16,8 +16,7 @@ out = os.path.join(g.PKG, "lib", "libbarbay_hip_stamps.so")
 stale = not os.path.exists(out) or any(os.path.getmtime(os.path.join(os.path.dirname(g.SRC), f)) > os.path.getmtime(out)
                                         for f in os.listdir(os.path.dirname(g.SRC)))
 if "--build-only" in sys.argv or stale:
-    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-DBB_STAMPS", "-fPIC", "-shared",
-                    "-Wl,-Bsymbolic", g.SRC, "-o", out, "-ldl"], check=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", *g.HIP_FLAGS, "-DBB_STAMPS", g.SRC, "-o", out, "-ldl"], check=True)
     if "--build-only" in sys.argv:
         sys.exit(0)
 import barbay_jl_amd as bb  # noqa: E402

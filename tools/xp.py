@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Experiment driver for kernel variants (diagnostic).
+   python tools/xp.py build NAME [-DFLAG ...]     here: lib/ab/NAME.so and NAME_st.so (-DBB_STAMPS), only the C2 / C4 instances (-DBB_FAST_BUILD)
+   python tools/xp.py run NAME [NAME ...]         on the GPU box: steps/s of C2 (WL=, B=, T= as tools/ab_geom.py) and the stamp shares"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+AB = os.path.join(g.PKG, "lib", "ab")
+if sys.argv[1] == "build":
+    os.makedirs(AB, exist_ok=True)
+    name, flags = sys.argv[2], sys.argv[3:]
+    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", *g.HIP_FLAGS, "-DBB_FAST_BUILD", *flags, *extra, g.SRC, "-o", os.path.join(AB, name + suf + ".so"), "-ldl"])
+          for suf, extra in (("", []), ("_st", ["-DBB_STAMPS"]))]
+    sys.exit(max(p.wait() for p in ps))
+
+import barbay_jl_amd as bb  # noqa: E402
+from barbay_jl_amd import _capi, synth  # noqa: E402
+
+WL = os.environ.get("WL", "fitness_normal")
+wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42) if WL == "fitness_normal" else getattr(synth, WL)()
+names = sys.argv[2:]
+PH = [(20, 21, "S"), (21, 23, "M"), (23, 24, "pub"), (24, 25, "X"), (25, 26, "F"), (26, 28, "G")]
+
+
+def engine(lib):
+    return bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=42, _lib=lib)
+
+
+for rep in range(2):
+    for name in names:
+        e = engine(_capi.load_library(os.path.join(AB, name + ".so")))
+        e.run(1000)
+        e.run(4000)
+        st = e.stats()
+        ms = st["last_run_ms"]
+        line = f"{name:14s} k{st['resident_kernel']} P{st['persistent_pairs']} x{st['block_threads']:4d} {4000 / ms * 1e3:9.1f} steps/s {ms / 4:7.3f} us"
+        e.close()
+        if rep == 1:
+            e = engine(_capi.load_library(os.path.join(AB, name + "_st.so")))
+            e.run(21)
+            s = e.stamps().astype(np.int64)
+            tot = np.median(s[:, 28] - s[:, 20])
+            line += f" | span {tot:6.0f}: " + " ".join(f"{nm} {np.median(s[:, b] - s[:, a]):5.0f}" for a, b, nm in PH if s[:, b].any() and s[:, a].any())
+            e.close()
+        print(line, flush=True)
