@@ -297,11 +297,17 @@ class Engine:
         self._check(self._lib.bb_debug_normals(self._h, step, stream, lo, hi, _ptr(out)))
         return out
 
-    def stamps(self) -> np.ndarray:
+    def stamps(self, per_wave: bool = False) -> np.ndarray:
+        """Diagnostic build only: [tiles][32] block stamps, or with per_wave [tiles][4 events][16 waves]."""
         nb = int(self.stats()["n_blocks"])
-        out = np.zeros((nb, 32), dtype=np.uint64)
-        self._check(self._lib.bb_debug_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), nb * 32))
-        return out
+        rows = np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.bb_debug_stamps(self._h, rows.ctypes.data_as(C.POINTER(C.c_uint64)), -1))
+        rows = int(rows[0])
+        raw = np.zeros(rows * 96, dtype=np.uint64)
+        self._check(self._lib.bb_debug_stamps(self._h, raw.ctypes.data_as(C.POINTER(C.c_uint64)), raw.size))
+        if not per_wave:
+            return raw[:nb * 32].reshape(nb, 32).copy()
+        return raw[rows * 32:rows * 32 + nb * 64].reshape(nb, 4, 16).copy()
 
     def stats(self) -> Dict[str, float]:
         s = bb_stats()

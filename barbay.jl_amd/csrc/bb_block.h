@@ -50,6 +50,13 @@ BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
 #define BB_STAMP_W(cx, S, i) ((void)0)
 #endif
 
+// per-wave stamps (diagnostic build only): event ev in 0..3 of every wave, behind the [tiles + 8][32] block stamps
+#if defined(BB_STAMPS) && !defined(BB_EMU)
+#define BB_STAMP_WAVE(cx, S, A, ev) do { if ((threadIdx.x & 63) == 0) (S).stamps[((long long)(A).nblk_alloc + 8) * 32 + (long long)(cx).block * 64 + (ev) * 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BB_STAMP_WAVE(cx, S, A, ev) ((void)0)
+#endif
+
 #include "bb_math.h"
 
 #define BB_STREAM_INIT_MU 0xFFFFFFFFu

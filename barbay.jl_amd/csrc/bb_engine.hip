@@ -251,6 +251,7 @@ struct bb_handle {
 #endif
     int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
     int res_P = 0;                     // > 0: the launch is k_res (bb_resident.h, owner-computes) with this many pair slots per thread
+    int res_NB = 0, res_NBL = 0, res_nblk = 0;   // ... its own tile map: barcodes per tile, per leader tile (0: uniform), tiles
     BRLay Yh{};                        // its LDS carve-up (host copy) and device copy
     BRLay* dY = nullptr;
     DevModel* dM = nullptr;            // device copies of the descriptors for the persistent launch
@@ -392,13 +393,20 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = fal
 
 #ifndef BB_EMU
 typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
-static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg) {
+static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
 #ifdef BB_FAST_BUILD
     if (xg) return nullptr;
-    if (nthr > 512 && P == 1) return kind == 0 ? k_res<0, 1, 1024, false> : (kind == 1 ? k_res<1, 1, 1024, false> : nullptr);
-    if (nthr > 256 && nthr <= 512 && P == 2 && kind == 0) return k_res<0, 2, 512, false>;
+    if (nthr > 512 && P == 1 && kind == 0) return T == 8 ? k_res<0, 1, 1024, false, 8> : k_res<0, 1, 1024, false>;
+    if (nthr > 512 && P == 1 && kind == 1) return T == 6 ? k_res<1, 1, 1024, false, 6> : k_res<1, 1, 1024, false>;
+    if (nthr > 256 && nthr <= 512 && P == 2 && kind == 0) return T == 8 ? k_res<0, 2, 512, false, 8> : k_res<0, 2, 512, false>;
     return nullptr;
 #else
+    // the BASELINE shapes' time-point counts as compile-time constants (the unit threads then read whole rows at once), in the
+    // geometries those workloads and their shards use; everything else reads T from the descriptor
+#define BR_T(K, PP, NT, TT) if (kind == (K) && P == (PP) && T == (TT)) return xg ? k_res<K, PP, NT, true, TT> : k_res<K, PP, NT, false, TT>;
+    if (nthr > 512) { BR_T(0, 1, 1024, 8) BR_T(0, 1, 1024, 6) BR_T(1, 1, 1024, 8) BR_T(1, 1, 1024, 6) }
+    else if (nthr > 256) { BR_T(0, 1, 512, 8) BR_T(0, 2, 512, 8) BR_T(1, 1, 512, 6) BR_T(1, 2, 512, 6) }
+#undef BR_T
 #define BR_CASE(K, PP, NT) case (K) * 10 + (PP): return xg ? k_res<K, PP, NT, true> : k_res<K, PP, NT, false>;
     if (nthr > 512) {          // 16 waves per CU: 128 registers per lane
         switch (kind * 10 + P) { BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) default: return nullptr; }
@@ -447,23 +455,41 @@ static bool try_resident(bb_handle* h) {
     const char* ev = getenv("BB_NO_RES");
     if (ev && atoi(ev) > 0) return false;
     if (!br_eligible(h->M)) return false;
-    const int P = (int)((br_tile_span(h->M, h->NB, true) + h->nthr - 1) / h->nthr);
+    // tile map: leaders (tiles 0 .. 7) hold `frac` of a tile's barcodes (br_tile); BB_TUNE_LEAD=100 keeps all tiles alike
+    int NB = h->NB, NBL = 0, nblk = h->nblk;
+    const long long nbar = std::max<long long>(h->b_hi - h->b_lo, 1);
+    int pct = (ev = getenv("BB_TUNE_LEAD")) ? atoi(ev) : 65;
+    if (pct < 10 || pct > 100) pct = 100;
+    const bool nb_fixed = getenv("BB_TUNE_NB") != nullptr;
+    if (pct < 100 && h->nblk >= 16 && (!nb_fixed || ev)) {
+        if (!nb_fixed) {
+            const double tiles = (double)h->nblk - 8.0 * (1.0 - pct / 100.0);      // in units of a full tile
+            NB = (int)std::ceil((double)nbar / tiles);
+        }
+        NBL = std::max(1, (int)(NB * (pct / 100.0)));
+        const long long rest = nbar - 8ll * NBL;
+        nblk = 8 + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
+        if (nblk > h->nblk + (nb_fixed ? 8 : 0)) { NB = h->NB; NBL = 0; nblk = h->nblk; }   // (rounding pushed it over the grid that fits: stay uniform)
+    }
+    const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
     if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
-    const BRLay Y = br_layout(h->M, h->NB, h->nthr, P);
+    const BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on);
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
-    if (P * (h->nthr / 64) >= 1024) return false;               // row map packs virtual-wave numbers into 10 bits
 #ifndef BB_EMU
-    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on);
+    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, h->M.T[0]);
     if (!k) return false;
     const int lds = Y.total * 8;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
     int per_cu = 0;
     hipDeviceProp_t pr;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, h->nthr, (size_t)lds) != hipSuccess ||
-        hipGetDeviceProperties(&pr, h->o.device) != hipSuccess || (long long)per_cu * pr.multiProcessorCount < h->nblk) return false;
+        hipGetDeviceProperties(&pr, h->o.device) != hipSuccess || (long long)per_cu * pr.multiProcessorCount < nblk) return false;
 #endif
     h->Yh = Y;
     h->res_P = P;
+    h->res_NB = NB;
+    h->res_NBL = NBL;
+    h->res_nblk = nblk;
     h->lds_doubles_p = (size_t)Y.total;
     return true;
 }
@@ -475,7 +501,7 @@ static int setup_persistent(bb_handle* h) {
     const char* why = nullptr;
     if (h->o.samples_per_step != 1) why = "samples_per_step != 1";
     else if (h->force_reduce || (h->o.world_size != 1 && !h->p2p_on)) why = "sharded run";
-    else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";
+    else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";   // (k_res's own tile map never has fewer tiles than this one)
     else if (h->o.elbo_every != 0) why = "ELBO recording is on";
     else if (h->M.kind == BB_MODEL_GENOTYPE) why = "genotype model (second exchange per step)";
     h->res_P = 0;
@@ -585,11 +611,11 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
     const unsigned long long step = (unsigned long long)(h->step + it);
     const int buf = (int)(step & 1);
     const bool xg = h->p2p_on;
-    for (int b = 0; b < (phase == 2 ? bbp_groups(h->nblk) : h->nblk); ++b) {
+    for (int b = 0; b < (phase == 2 ? bbp_groups(h->res_nblk) : h->res_nblk); ++b) {
         BBCtx cx = cxof(b);
         BRSt<PP>* sb = st + (size_t)b * h->nthr;
         if (phase == 0) {
-            br_prologue<KIND, PP>(cx, h->M, h->S, A, Y, h->NB, sb);
+            br_prologue<KIND, PP>(cx, h->M, h->S, A, Y, h->res_NB, sb);
             br_draw_ahead<PP>(cx, A, Y, sb, (unsigned long long)h->step);
         } else if (phase == 1) {
             br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
@@ -601,7 +627,10 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
         } else if (phase == 3) {
             if (xg) br_xchg_consume<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             else br_xchg_consume<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
-            br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf);
+            // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
+            if (h->M.T[0] == 8) br_update<KIND, PP, 8>(cx, h->M, h->S, A, Y, sb, step, buf);
+            else if (h->M.T[0] == 6) br_update<KIND, PP, 6>(cx, h->M, h->S, A, Y, sb, step, buf);
+            else br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf);
         } else {
             br_epilogue<PP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
@@ -653,8 +682,9 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
         bb_handle* h = hs[i];
         es[i].h = h;
         es[i].A = make_args(h, h->step, 0, 1, true, false);
-        es[i].lds.assign((size_t)h->nblk * (h->lds_doubles_p + 64), 0.0);
-        es[i].st.assign((size_t)h->nblk * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
+        if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; }
+        es[i].lds.assign((size_t)std::max(h->nblk, h->res_nblk) * (h->lds_doubles_p + 64), 0.0);
+        es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
     }
     for (long long it = 0; it < nsteps; ++it)
@@ -692,11 +722,12 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
-    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on) : nullptr;
+    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, h->M.T[0]) : nullptr;
+    if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
-        if (kr) hipLaunchKernelGGL(kr, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->NB, n);
+        if (kr) hipLaunchKernelGGL(kr, dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n);
         else hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB, n);
         rc = launch_check();
         h->step += n;
@@ -977,7 +1008,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &S.gacc_om, D + 2));
     BB_TRY(dalloc(h, &h->bak_mu, D + 2));
     BB_TRY(dalloc(h, &h->bak_om, D + 2));
-    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dp));
+    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dp + 8));   // (+ 8: an edge pair's prefetch reads both halves)
     BB_TRY(dalloc(h, &S.partials, (size_t)M.K * (size_t)h->nblk));
     BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
     BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
@@ -999,9 +1030,9 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         S.hstatus = (unsigned*)dp;
     }
 #endif
-    BB_TRY(dalloc(h, &S.prow, (size_t)h->nblk * (M.K + 2 * M.nt1)));
+    BB_TRY(dalloc(h, &S.prow, (size_t)(h->nblk + 8) * (M.K + 2 * M.nt1)));      // (+ 8: k_res's own tile map may need a few tiles more)
     BB_TRY(dalloc(h, &S.xrow, (size_t)2 * 8 * (M.K + 2 * M.nt1)));
-    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 16)));
+    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 16)));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));
@@ -1009,7 +1040,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &S.elbo_ring, (size_t)BB_ELBO_RING));
     BB_TRY(dalloc(h, &S.elbo_sample, (size_t)opts->samples_per_step + 64));
     BB_TRY(dalloc(h, &S.ctr, (size_t)2));
-    BB_TRY(dalloc(h, &S.stamps, (size_t)h->nblk * 32));
+    BB_TRY(dalloc(h, &S.stamps, (size_t)(h->nblk + 8) * (32 + 64)));
     S.eps_in = nullptr;
 
     // algorithmic bytes per step on this shard: theta r+w, optimiser state r+w, counts
@@ -1077,6 +1108,7 @@ static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, 
     A.xepoch0 = h->epoch0;
     A.spin_limit = 1u << 23;                  // ~1 us per poll: seconds, not milliseconds
     A.nblk = h->nblk;
+    A.nblk_alloc = h->nblk;
     A.par = (int)(step & 1);
     A.sample = sample;
     A.S = S;
@@ -1528,9 +1560,10 @@ extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int
 }
 
 extern "C" int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n) {
-    if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (!h || !out) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (n < 0) { out[0] = (uint64_t)(h->nblk + 8); return BB_OK; }     // rows of the block-stamp area (the per-wave area follows it)
     BB_ENTER(h);
-    const int64_t have = (int64_t)h->nblk * 32;
+    const int64_t have = (int64_t)(h->nblk + 8) * (32 + 64);
     int rc = dsync(h->stream);
     if (rc) return rc;
     return d2h(out, h->S.stamps, (size_t)std::min(n, have) * 8, h->stream);
@@ -1748,7 +1781,7 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->last_run_ms = h->last_run_ms;
     s->avg_sample_ms = h->avg_sample_ms;
     s->avg_update_ms = h->avg_update_ms;
-    s->n_blocks = h->nblk;
+    s->n_blocks = h->res_P ? h->res_nblk : h->nblk;
     s->block_threads = h->nthr;
     s->lds_bytes = (int32_t)((h->persist_P > 0 ? h->lds_doubles_p : h->lds_doubles) * 8);
     s->persistent_pairs = h->persist_P;

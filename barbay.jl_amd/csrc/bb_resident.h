@@ -43,18 +43,28 @@
 #endif
 #define BR_MAXT 16
 
-struct BRSeg { long long lo, hi; int tbeg, span, blk, kind, ldsoff, r, lpb, T; };   // 48 B = 6 doubles
+// (the prior of the segment's block travels with it: read per latent in the G pass, it must come from LDS -- fetched through the
+// model descriptor with a per-lane block index it was a chain of five dependent global loads per pair and step)
+struct BRSeg { long long lo, hi; int tbeg, span, blk, kind, ldsoff, r, lpb, T; double pm, iv; const double* mean_e; const double* iv_e; long long blo; };   // 88 B = 11 doubles
+#define BR_SEG_DOUBLES 11
 
 struct BRLay {
     BBLds L;             // what the shared exchange / finish code reads: wk, zgl, Lt, invS, cc, wbar, gglob, Dt, elbt, misc, acc, red
-    int zl, NBT;         // [2][NBT] staged loglambda samples (NBT = NB * Ttot), double-buffered by step parity
-    int st[4], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w
+    int zl, NBT;         // [2][NBT] staged loglambda samples, double-buffered by step parity; replicate r's rows start at zr0[r] and are
+    int zr0[BB_MAX_REP]; // T_r + 1 doubles apart: with the natural stride T_r (8: 64 B) the unit threads' walks along their barcodes'
+                         // rows (two barcodes per lane) land all 64 lanes in two banks -- measured: the unit waves' G pass took
+                         // 14 k cycles against 5 k for the loglambda waves
+    int st[4], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w, 2 = logsigma
                          //                                  hierarchical        0 = theta_tilde, 1 = e^logtau, 2 = w, 3 = theta
     int eps;             // [P * NT] bb_d2: the next step's normals
+    int hbuf;            // [P][2][NT] bb_d2: this step's TruncatedADAGrad window slot, fetched by LDS-DMA while the exchange is in flight
+                         // (no registers held across the exchange); shares the moment contributions' region (dead by then) unless the
+                         // cross-GPU inbox staging needs it at the same time
     int racc, rstride, rwidth;   // [12][rstride] the moment contributions of threads 0 .. rwidth-1 (the loglambda lanes), transposed;
                          // rstride = rwidth + 4: the 12 columns start in different banks
     int rowmap;          // [K] ints: time-pair class k | value index v << 8 | used << 16
     int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
+    int envt;            // [Ttot] ints: environment of every time point (multienv)
     int seg;             // BRSeg table
     int total;
     int lpb[BB_MAX_REP];
@@ -87,7 +97,7 @@ static inline
 #ifndef BB_EMU
 __host__ __device__
 #endif
-BRLay br_layout(const DevModel& M, int NB, int NT, int P) {
+BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     BRLay Y;
     const int X = (M.kind == 1) ? M.E : (M.kind == 4 ? M.E * M.R : M.R);
     const int KK = M.K + 2 * M.nt1;
@@ -96,10 +106,12 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P) {
     for (int r = 0; r < BB_MAX_REP; ++r) { Y.lpb[r] = r < M.R ? br_pow2_ge(M.T[r] / 2) : 1; if (Y.lpb[r] > lmax) lmax = Y.lpb[r]; }
     BBLds& L = Y.L;
     L = BBLds{};
-    Y.NBT = NB * M.Ttot;
+    Y.NBT = 0;
+    for (int r = 0; r < BB_MAX_REP; ++r) { Y.zr0[r] = Y.NBT; if (r < M.R) Y.NBT += NB * (M.T[r] + 1); }
+    Y.NBT = (Y.NBT + 1) & ~1;
     Y.zl = o;      o += 2 * Y.NBT;
     Y.SU = NB * X;
-    Y.nst = M.kind <= 1 ? 2 : 4;
+    Y.nst = M.kind <= 1 ? 3 : 4;
     for (int i = 0; i < 4; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
     o = (o + 1) & ~1;
     Y.eps = o;     o += 2 * P * NT;
@@ -123,13 +135,15 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P) {
     L.elbt = o;    o += M.Ttot;
     Y.iG = o;      o += M.Ttot;
     Y.csum = o;    o += BB_MAX_REP;
-    Y.seg = o;     o += 6 * (BB_MAX_SEG + 1);
+    Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
+    Y.seg = o;     o += BR_SEG_DOUBLES * (BB_MAX_SEG + 1);
     L.seg = Y.seg;
     o = (o + 1) & ~1;
     // one transient region, two users that never overlap in time: the transposed moment contributions (M pass -> row sums) and the
     // staging of the cross-GPU inbox rows (bbp_consume<true>)
-    Y.racc = L.acc = o;
-    o += BR_NCV * Y.rstride > (BB_NQ + 1) * NT ? BR_NCV * Y.rstride : (BB_NQ + 1) * NT;
+    Y.racc = Y.hbuf = o;
+    { const int need = BR_NCV * Y.rstride > 4 * P * NT ? BR_NCV * Y.rstride : 4 * P * NT; o += need; }
+    L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;
     L.red = o;     o += KK + 16;
     (void)lmax;
     L.total = Y.total = (o + 1) & ~1;
@@ -140,11 +154,8 @@ template <int P>
 struct BRSt {
     bb_d2 mu[P], om[P], am[P], ao[P];   // variational parameters and optimiser accumulators
     bb_d2 a[P], h[P];                   // eps * sigmoid(omega), sigmoid / softplus of the current draw
-    bb_d2 hm[P], ho[P];                 // this step's window slot (prefetched during the exchange)
-    bb_d2 z[P];                         // the pair's samples
+    bb_d2 z[P];                         // the pair's samples (alive from S to M only: the G pass re-reads what it needs from LDS)
     bb_d2 lam[P];                       // loglambda pairs: e^z
-    double ap[P], amid[P], an[P];       // loglambda pairs: a = dl - s_eff of the backward / inner / forward difference
-    double wp[P], wm[P], wn[P];         // ... and the mutant's precisions there
     long long i0[P];
     int meta[P];                        // seg kind | a0 << 4 | a1 << 5 | valid << 6 | mutant << 7 | has_prev << 8 | has_next << 9 | seg index << 12
     int zoff[P];                        // loglambda: offset of z0 inside one zl buffer; unit pairs: index of latent 0 inside its stage table
@@ -156,6 +167,26 @@ struct BRSt {
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
 
+// Tile map of k_res.  The group leaders of the exchange (tiles 0 .. 7) do extra work between their publish and everybody's
+// consume; with nbl < NB barcodes they reach their publish early enough to have drawn their next normals before their members'
+// rows arrive, and the group rows appear one draw (~5 k cycles) sooner for all tiles.
+BB_DEV BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
+    if (A.nbl <= 0) return bb_tile(M, A, block, NB);
+    const int nlead = A.nblk < 8 ? A.nblk : 8;
+    BBTile t;
+    t.NB = NB;
+    const int cap = block < nlead ? A.nbl : NB;
+    t.b0 = block < nlead ? A.b_lo + (long long)block * A.nbl : A.b_lo + (long long)nlead * A.nbl + (long long)(block - nlead) * NB;
+    long long b1 = t.b0 + cap < A.b_hi ? t.b0 + cap : A.b_hi;
+    if (t.b0 > A.b_hi) t.b0 = A.b_hi;
+    t.nbt = (int)(b1 > t.b0 ? b1 - t.b0 : 0);
+    long long ns = M.nn - t.b0;
+    t.nshift = (int)(ns < 0 ? 0 : (ns > t.nbt ? t.nbt : ns));
+    t.m0 = t.b0 + t.nshift - M.nn;
+    t.nmt = t.nbt - t.nshift;
+    return t;
+}
+
 // ---- segment table of a tile in the padded thread-index space (one thread) --------------------------------------
 template <int KIND>
 BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTile& t, bool globals) {
@@ -164,6 +195,7 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
         if (cnt <= 0) return;
         BRSeg s;
         s.lo = lo; s.hi = lo + cnt; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.lpb = lpb; s.T = T;
+        s.pm = M.pri[blk].mean; s.iv = M.pri[blk].inv_var; s.mean_e = M.pri[blk].mean_e; s.iv_e = M.pri[blk].inv_var_e; s.blo = M.blk_lo[blk];
         if (kind == SK_L) { cur = (cur + 63) & ~63; s.span = (int)(cnt / T) * lpb; }
         else s.span = bb_seg_pairs(lo, lo + cnt);
         s.tbeg = cur;
@@ -171,7 +203,7 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
         sg[n++] = s;
     };
     for (int r = 0; r < M.R; ++r)
-        add(BK_L, SK_L, M.off_l[r] + t.b0 * M.T[r], (long long)t.nbt * M.T[r], t.NB * M.tcum[r], r, Y.lpb[r], M.T[r]);
+        add(BK_L, SK_L, M.off_l[r] + t.b0 * M.T[r], (long long)t.nbt * M.T[r], Y.zr0[r], r, Y.lpb[r], M.T[r]);
     if (t.nmt > 0) {
         if (KIND == 0 || KIND == 1) {
             const int E = KIND == 1 ? M.E : 1;
@@ -192,7 +224,7 @@ template <int KIND, int P>
 BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, BRSt<P>* stv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
-    const BBTile t = bb_tile(M, A, cx.block, NB);
+    const BBTile t = br_tile(M, A, cx.block, NB);
     BRSeg* sg = (BRSeg*)(lds + Y.seg);
     int* li = (int*)(lds + L.misc);
     const int KK = M.K + 2 * M.nt1;
@@ -203,6 +235,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
         for (int i = tid; i < 2 * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
         for (int i = tid; i < 2 * Y.nst * Y.SU; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
         if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
+        if (tid < M.Ttot) ((int*)(lds + Y.envt))[tid] = KIND == 1 ? M.env_idx[tid] : 0;
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
@@ -238,7 +271,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                         const int t0 = 2 * kk;
                         i0 = s.lo + (long long)bl * s.T + t0;
                         meta |= BRM_A0 | BRM_A1 | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);
-                        st.zoff[k] = s.ldsoff + bl * s.T + t0;
+                        st.zoff[k] = s.ldsoff + bl * (s.T + 1) + t0;
                         st.pt[k] = M.tcum[s.r] + t0;
                         if (bl >= t.nshift) {
                             meta |= BRM_MUT;
@@ -266,7 +299,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                             int j = st.zoff[k] + x;
                             if (j < 0) j = 0;
                             const int ml = j / E, e = j - ml * E;
-                            st.uo[k][x] = (t.nshift + ml) * M.T[0];
+                            st.uo[k][x] = Y.zr0[0] + (t.nshift + ml) * (M.T[0] + 1);
                             env |= e << (8 * x);
                         }
                         st.uo[k][2] = env;
@@ -280,8 +313,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.om[k] = bb_load_pair(S.om, i0, a0, a1);
             st.am[k] = bb_load_pair(S.acc_mu, i0, a0, a1);
             st.ao[k] = bb_load_pair(S.acc_om, i0, a0, a1);
-            st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
-            st.ap[k] = st.amid[k] = st.an[k] = st.wp[k] = st.wm[k] = st.wn[k] = 0.0;
+            st.a[k] = st.h[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
         }
     }
     BB_SYNC(cx);
@@ -326,6 +358,7 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     BB_STAMP(cx, S, 20);
+    BB_STAMP_WAVE(cx, S, A, 1);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
@@ -349,12 +382,18 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             if (!(meta & BRM_VALID)) continue;
             const int kind = meta & 15;
             if (kind == SK_L) {
-                *(bb_d2*)(lds + Y.zl + buf * Y.NBT + st.zoff[k]) = st.z[k];      // zoff is even: T even, aligned segments
+                double* zw = lds + Y.zl + buf * Y.NBT + st.zoff[k];                // (rows are T + 1 apart: 8-byte aligned only)
+                zw[0] = st.z[k].x;
+                zw[1] = st.z[k].y;
             } else if (kind == SK_S || kind == SK_LS_E) {
-                double* dst = lds + Y.st[kind == SK_S ? 0 : 1] + buf * Y.SU + st.zoff[k];
-                const bb_d2 v = kind == SK_S ? st.z[k] : st.lam[k];
-                if (meta & BRM_A0) dst[0] = v.x;
-                if (meta & BRM_A1) dst[1] = v.y;
+                double* dst = lds + Y.st[kind == SK_S ? 0 : 2] + buf * Y.SU + st.zoff[k];
+                if (meta & BRM_A0) dst[0] = st.z[k].x;
+                if (meta & BRM_A1) dst[1] = st.z[k].y;
+                if (kind == SK_LS_E) {
+                    double* dw = lds + Y.st[1] + buf * Y.SU + st.zoff[k];
+                    if (meta & BRM_A0) dw[0] = st.lam[k].x;
+                    if (meta & BRM_A1) dw[1] = st.lam[k].y;
+                }
             } else {      // replicated global latents (tile 0 only): they ride along in the tile's row, every other tile adds +0.0
                 double* dst = lds + L.wk + M.K + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
                 if (A.count_globals) {     // (sharded run: rank 0's draw is THE draw)
@@ -364,6 +403,7 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             }
         }
     }
+    BB_STAMP_WAVE(cx, S, A, 0);
     BB_SYNC(cx);                     // barrier 1: neighbours' z and the unit stages are visible
     BB_STAMP(cx, S, 21);
 }
@@ -402,32 +442,30 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
             const int meta = st.meta[k];
             if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
             const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
-            const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+            const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
             const double z0 = st.z[k].x, z1 = st.z[k].y;
-            const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
-            double dp = z0 - zp, dm = z1 - z0, dn = zn - z1;
+            const double zn = hn ? zb[2] : z1;
+            double dm = z1 - z0, dn = zn - z1;       // the pair's two forward differences (the backward one of z0 belongs to the previous pair)
             cv[0] += st.lam[k].x;
             cv[6] += st.lam[k].y;
             if (mut) {
                 const double* ts = lds + Y.st[0] + buf * Y.SU;
                 const double* tw = lds + Y.st[1] + buf * Y.SU;
-                double wp, wm, wn;
+                double wm, wn;
                 if (KIND == 1) {
-                    dp -= ts[st.uo[k][0]]; dm -= ts[st.uo[k][1]]; dn -= ts[st.uo[k][2]];
-                    wp = tw[st.uo[k][0]]; wm = tw[st.uo[k][1]]; wn = tw[st.uo[k][2]];
+                    dm -= ts[st.uo[k][1]]; dn -= ts[st.uo[k][2]];
+                    wm = tw[st.uo[k][1]]; wn = tw[st.uo[k][2]];
                 } else {
                     const double s = ts[st.uo[k][1]];
-                    wp = wm = wn = tw[st.uo[k][1]];
-                    dp -= s; dm -= s; dn -= s;
+                    wm = wn = tw[st.uo[k][1]];
+                    dm -= s; dn -= s;
                 }
-                st.wp[k] = wp; st.wm[k] = wm; st.wn[k] = wn;
                 cv[1] += wm; cv[2] += wm * dm; cv[3] += wm * dm * dm;
                 if (hn) { cv[7] += wn; cv[8] += wn * dn; cv[9] += wn * dn * dn; }
             } else {
                 cv[4] += dm; cv[5] += dm * dm;
                 if (hn) { cv[10] += dn; cv[11] += dn * dn; }
             }
-            st.ap[k] = dp; st.amid[k] = dm; st.an[k] = dn;
         }
         if (tid < Y.rwidth) {
 #pragma unroll
@@ -460,20 +498,28 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
     BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
 }
 
-// ---- window-slot prefetch (in the exchange's shadow) ----------------------------------------------------------------------
+// ---- window-slot prefetch (in the exchange's shadow): LDS-DMA, 16 bytes per lane straight into LDS, no register held across the
+// exchange.  Every pair slot fetches both halves of its 16-byte pair (the row is padded: an edge pair's outside half is a
+// neighbour's or the padding, never used). --------------------------------------------------------------------------------------
 template <int P>
-BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, BRSt<P>* stv, unsigned long long step) {
+BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+    if (A.opt != 0) return;
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
-        if (A.opt == 0) {
-            const int slot = bb_slot_of(A, step).slot;
-            const double* hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dp;
-            const double* hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
+        const int slot = bb_slot_of(A, step).slot;
 #pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const bool a0 = st.meta[k] & BRM_A0, a1 = st.meta[k] & BRM_A1;
-                st.hm[k] = bb_load_pair(hs_m, st.i0[k], a0, a1);
-                st.ho[k] = bb_load_pair(hs_o, st.i0[k], a0, a1);
+        for (int k = 0; k < P; ++k) {
+            if (!(st.meta[k] & BRM_VALID)) continue;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const double* src = S.hist + ((long long)slot * 2 + which) * M.Dp + st.i0[k];
+                bb_d2* dst = (bb_d2*)(cx.lds + Y.hbuf) + (k * 2 + which) * cx.nthr;
+#ifdef BB_EMU
+                dst[tid] = bb_d2{src[0], src[1]};
+#else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + (tid & ~63)), 16, 0, 0);
+#endif
             }
         }
     }
@@ -517,12 +563,16 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
 }
 
 // ---- G: gradients from registers, prior, optimiser, window slot -----------------------------------------------------------
-template <int KIND, int P>
+// TT > 0: the number of time points is a compile-time constant -- the unit threads then fetch their barcodes' whole rows at once
+// (with the row walk as a runtime loop, one LDS round trip per time step, the unit waves' G pass took 13 k cycles against 4 k
+// for the loglambda waves and the whole tile waited for them).
+template <int KIND, int P, int TT = 0>
 BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                       unsigned long long step, int buf) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBSlot wslot = bb_slot_of(A, step);
+    BB_STAMP_WAVE(cx, S, A, 2);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
         double* hs_m = nullptr;
@@ -531,69 +581,102 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dp;
             hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
         }
-        const int E = KIND == 1 ? M.E : 1;
+        const double* zbuf = lds + Y.zl + buf * Y.NBT;
+        const double* ts = lds + Y.st[0] + buf * Y.SU;       // s
+        const double* tw = lds + Y.st[1] + buf * Y.SU;       // w = e^{-2 logsigma}
+        const double* tl = lds + Y.st[2] + buf * Y.SU;       // logsigma
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int meta = st.meta[k];
             if (!(meta & BRM_VALID)) continue;
             const int kind = meta & 15;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
-            const int blk = sg[meta >> 12].blk;
-            const long long blo = M.blk_lo[blk];
-            double g0 = 0.0, g1 = 0.0;
+            const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
+            // prior of the pair's two latents: Vector form from the segment (LDS, one address per wave mostly), Matrix form per element
+            double pm0 = sgk->pm, pm1 = pm0, iv0 = sgk->iv, iv1 = iv0;
+            if (sgk->mean_e) {
+                const long long j = st.i0[k] - sgk->blo;
+                if (a0) { pm0 = sgk->mean_e[j]; iv0 = sgk->iv_e[j]; }
+                if (a1) { pm1 = sgk->mean_e[j + 1]; iv1 = sgk->iv_e[j + 1]; }
+            }
+            double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
             if (kind == SK_L) {
+                // everything but lambda is re-read from LDS (the staged samples are still there): differences, a = dl - s_eff, r = a - c
                 const int pt = st.pt[k];
                 const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
-                double wp = st.wp[k], wm = st.wm[k], wn = st.wn[k];
-                if (!mut) { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
-                const double rp = hp ? wp * (st.ap[k] - lds[L.cc + pt - 1]) : 0.0;
-                const double rm = wm * (st.amid[k] - lds[L.cc + pt]);
-                const double rn = hn ? wn * (st.an[k] - lds[L.cc + pt + 1]) : 0.0;
+                const double* zb = zbuf + st.zoff[k];
+                z0 = zb[0]; z1 = zb[1];
+                const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
+                double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
+                if (mut) {
+                    if (KIND == 1) {
+                        ap -= ts[st.uo[k][0]]; am -= ts[st.uo[k][1]]; an -= ts[st.uo[k][2]];
+                        wp = tw[st.uo[k][0]]; wm = tw[st.uo[k][1]]; wn = tw[st.uo[k][2]];
+                    } else {
+                        const double sb = ts[st.uo[k][1]];
+                        wp = wm = wn = tw[st.uo[k][1]];
+                        ap -= sb; am -= sb; an -= sb;
+                    }
+                } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
+                const double rp = hp ? wp * (ap - lds[L.cc + pt - 1]) : 0.0;
+                const double rm = wm * (am - lds[L.cc + pt]);
+                const double rn = hn ? wn * (an - lds[L.cc + pt + 1]) : 0.0;
                 const double l0 = st.lam[k].x, l1 = st.lam[k].y;
                 g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm - rp;
                 g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn - rm;
             } else if (kind == SK_S || kind == SK_LS_E) {
                 // per-unit sums over the time steps that use the unit:  As = w sum r,  Qs = w sum r^2 - n,  r = dl - s - c_t
-                const int T = M.T[0], T1 = T - 1;
-                const double* zbuf = lds + Y.zl + buf * Y.NBT;
+                const int T = TT ? TT : M.T[0], T1 = T - 1;
+                const int* envt = (const int*)(lds + Y.envt);
+                double gx[2] = {0.0, 0.0}, zx[2] = {0.0, 0.0};
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                     if (!(x ? a1 : a0)) continue;
                     const int j = st.zoff[k] + x;
                     const int e = (st.uo[k][2] >> (8 * x)) & 255;
                     const double* zr = zbuf + st.uo[k][x];
-                    double s, w;
-                    if (kind == SK_S) { s = x ? st.z[k].y : st.z[k].x; w = lds[Y.st[1] + buf * Y.SU + j]; }
-                    else { w = x ? st.lam[k].y : st.lam[k].x; s = lds[Y.st[0] + buf * Y.SU + j]; }
+                    const double sv = ts[j], wv = tw[j];
+                    zx[x] = kind == SK_S ? sv : tl[j];
                     double As = 0.0, Qs = 0.0;
-                    int n = 0;
-                    for (int tt = 0; tt < T1; ++tt) {
-                        if (KIND == 1 && M.env_idx[tt + 1] != e) continue;
-                        const double rr = (zr[tt + 1] - zr[tt]) - s - lds[L.cc + tt];
-                        As += rr; Qs += rr * rr; ++n;
+                    int nn = 0;
+                    if (TT) {
+                        double zrow[TT ? TT : 1];
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) zrow[tt] = zr[tt];          // the whole row in flight at once
+#pragma unroll
+                        for (int tt = 0; tt < TT - 1; ++tt) {
+                            const bool use = KIND != 1 || envt[tt + 1] == e;
+                            const double rr = use ? (zrow[tt + 1] - zrow[tt]) - sv - lds[L.cc + tt] : 0.0;
+                            As += rr; Qs += rr * rr; nn += use ? 1 : 0;
+                        }
+                    } else {
+                        for (int tt = 0; tt < T1; ++tt) {
+                            if (KIND == 1 && envt[tt + 1] != e) continue;
+                            const double rr = (zr[tt + 1] - zr[tt]) - sv - lds[L.cc + tt];
+                            As += rr; Qs += rr * rr; ++nn;
+                        }
                     }
-                    const double g = kind == SK_S ? w * As : w * Qs - (double)n;
-                    if (x) g1 = g; else g0 = g;
+                    gx[x] = kind == SK_S ? wv * As : wv * Qs - (double)nn;
                 }
-                (void)E;
+                g0 = gx[0]; g1 = gx[1]; z0 = zx[0]; z1 = zx[1];
             } else {
+                // the replicated global latents' sample came back with the totals (rank 0's draw)
                 const double* gg = lds + L.gglob + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
-                if (a0) g0 = gg[0];
-                if (a1) g1 = gg[1];
-            }
-            // the replicated global latents' sample came back with the totals (rank 0's draw); everybody else kept its own
-            double z0 = st.z[k].x, z1 = st.z[k].y;
-            if (kind >= SK_GS) {
                 const double* zz = lds + L.zgl + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[k];
-                if (a0) z0 = zz[0];
-                if (a1) z1 = zz[1];
+                if (a0) { g0 = gg[0]; z0 = zz[0]; }
+                if (a1) { g1 = gg[1]; z1 = zz[1]; }
             }
-            double pm, iv;
-            if (a0) { bb_prior_of(M, blk, st.i0[k] - blo, &pm, &iv); g0 -= (z0 - pm) * iv; }
-            if (a1) { bb_prior_of(M, blk, st.i0[k] + 1 - blo, &pm, &iv); g1 -= (z1 - pm) * iv; }
+            g0 -= (z0 - pm0) * iv0;
+            g1 -= (z1 - pm1) * iv1;
             const double go0 = fma(g0, st.a[k].x, st.h[k].x), go1 = fma(g1, st.a[k].y, st.h[k].y);
-            const bb_d2 hm = hs_m ? st.hm[k] : bb_d2{0, 0}, ho = hs_m ? st.ho[k] : bb_d2{0, 0};
+            bb_d2 hm{0, 0}, ho{0, 0};
+            if (hs_m) {
+#ifndef BB_EMU
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA of the window slot has landed (br_prefetch_slot)
+#endif
+                hm = ((const bb_d2*)(lds + Y.hbuf))[(k * 2 + 0) * cx.nthr + tid];
+                ho = ((const bb_d2*)(lds + Y.hbuf))[(k * 2 + 1) * cx.nthr + tid];
+            }
             bb_d2 nhm = hm, nho = ho;
             if (a0) {
                 bb_opt_apply(M, S, A, wslot, 0, st.i0[k], -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x);
@@ -610,6 +693,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             if (hs_m) { bb_store_pair(hs_m, st.i0[k], a0, a1, nhm); bb_store_pair(hs_o, st.i0[k], a0, a1, nho); }
         }
     }
+    BB_STAMP_WAVE(cx, S, A, 3);
     BB_STAMP(cx, S, 28);
 }
 
@@ -641,6 +725,9 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
 template <int P>
 BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+    // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
+    // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
+    br_prefetch_slot<P>(cx, M, S, A, Y, stv, step);
     br_draw_ahead<P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
 }
 template <bool XG>
@@ -652,13 +739,12 @@ template <int KIND, int P, bool XG>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                             unsigned long long step, int* ok_slot) {
     const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
-    br_prefetch_slot<P>(cx, M, S, A, stv, step);           // cold window lines fly while the rows arrive
     bbp_consume<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
     br_finish<KIND>(cx, M, S, Y);
 }
 
 #ifndef BB_EMU
-template <int KIND, int P, int NT, bool XG = false>
+template <int KIND, int P, int NT, bool XG = false, int TT = 0>
 __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, const BRLay* __restrict__ Yp,
                                             RunArgs A, int NB, int nsteps) {
     const DevModel& M = *Mp;
@@ -684,7 +770,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
             if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
-            br_update<KIND, P>(cx, M, S, A, Y, &st, step, buf);
+            br_update<KIND, P, TT>(cx, M, S, A, Y, &st, step, buf);
         }
     }
     br_epilogue<P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);

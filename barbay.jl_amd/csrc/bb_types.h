@@ -73,7 +73,7 @@ struct DevState {
     double *prow;                     // [nblk][K + 2 nt1] rows of the tiles (persistent launch)
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
-    unsigned long long *stamps;       // [nblk][32] s_memtime stamps (diagnostic build -DBB_STAMPS only)
+    unsigned long long *stamps;       // [nblk + 8][32] s_memtime stamps, then [nblk + 8][4][16] per-wave stamps (diagnostic build -DBB_STAMPS only)
     // cross-GPU leg of the resident launch's exchange (bb_p2p_*): every rank owns an INBOX -- group rows
     // [2 parity][world][8 groups][K + 2 nt1] and their ready words [2][world][8] (one 128-B line each) -- in
     // fine-grained memory that its peers map through IPC handles; xout[r] / xout_rdy[r] are rank r's inbox as
@@ -90,6 +90,8 @@ struct RunArgs {
     unsigned xepoch0;                 // base of the ready / inbox words of the resident launch: they carry base + step + 1 and only ever grow (bb_persist.h)
     unsigned spin_limit;              // polls of one ready word before a resident launch gives up (the first launch of a sharded run gets more)
     int nblk;                         // blocks of the barcode grid
+    int nblk_alloc;                   // tiles the exchange / stamp buffers were sized for (+ 8)
+    int nbl;                          // k_res: barcodes of each of the first min(8, nblk) tiles -- the exchange's group leaders get smaller tiles (0: all tiles alike)
     int par;                          // which ctr[] word holds the current step
     int sample, S;
     int first_sample, last_sample;    // of this step

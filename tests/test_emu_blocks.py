@@ -77,6 +77,18 @@ def test_owner_computes_launch_geometries(emu_lib, monkeypatch, nb, nthr):
     c.case_persistent_equals_two_kernel(emu_lib, "multienv_T8", expect_kernel=2)
 
 
+@pytest.mark.parametrize("lead", [50, 65, 13])
+def test_owner_computes_launch_smaller_leader_tiles(emu_lib, monkeypatch, lead):
+    """k_res's own tile map: the exchange's group leaders (tiles 0 .. 7) hold fewer barcodes (neutral / mutant boundary inside
+    a leader tile, a last tile that is nearly empty); results must not depend on it."""
+    monkeypatch.setenv("BB_TUNE_NB", "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    monkeypatch.setenv("BB_TUNE_LEAD", str(lead))
+    c.case_persistent_equals_two_kernel(emu_lib, "fitness_T6", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(emu_lib, "multienv_T8", expect_kernel=2)
+    c.case_p2p_resident(emu_lib, "fitness_T6", 2)
+
+
 def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NB", "120")     # 120 barcodes x (16 + 1 + 9) latents / 2 > 1024 pairs -> P = 2
     monkeypatch.setenv("BB_TUNE_NTHR", "1024")

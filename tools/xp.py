@@ -48,5 +48,25 @@ for rep in range(2):
             s = e.stamps().astype(np.int64)
             tot = np.median(s[:, 28] - s[:, 20])
             line += f" | span {tot:6.0f}: " + " ".join(f"{nm} {np.median(s[:, b] - s[:, a]):5.0f}" for a, b, nm in PH if s[:, b].any() and s[:, a].any())
+            lead = np.arange(s.shape[0]) < 8
+            line += (f"\n     leaders: publish->members seen {np.median(s[lead, 17] - s[lead, 24]):.0f}, read+sum+store+flag {np.median(s[lead, 18] - s[lead, 17]):.0f}, "
+                     f"then until group rows seen {np.median(s[lead, 1] - s[lead, 18]):.0f}; others: publish->group rows seen {np.median(s[~lead, 1] - s[~lead, 24]):.0f}, "
+                     f"rows read+sum {np.median(s[:, 25] - s[:, 1]):.0f}; leaders publish earlier than others by {np.median(s[~lead, 24]) - np.median(s[lead, 24]):.0f}")
+            # (s_memtime counters differ between XCDs: compare tiles of one XCD only -- tiles b = 3 mod 8 under round-robin placement)
+            grp = np.arange(3, s.shape[0], 8)
+            for ev, nm in ((24, "publish"), (25, "rows seen+read"), (28, "G end")):
+                tt = s[grp, ev] - s[grp, ev].min()
+                line += f"\n     {nm:15s} spread over the tiles = 3 mod 8 (after the first): median {np.median(tt):.0f} p90 {np.percentile(tt, 90):.0f} max {tt.max()} (tile {grp[int(np.argmax(tt))]}); leader tile 3: {tt[0]}"
+            if os.environ.get("WAVES"):
+                w = e.stamps(per_wave=True).astype(np.int64)
+                for b in [int(x) for x in os.environ["WAVES"].split(",")]:
+                    t0 = s[b, 26]
+                    line += (f"\n     tile {b} (relative to F-done of the last step; S of that step came before):"
+                             + f"\n       S-start " + " ".join(f"{v:6d}" for v in (w[b, 1] - t0))
+                             + f"\n       S-end   " + " ".join(f"{v:6d}" for v in (w[b, 0] - t0))
+                             + f"\n       S len   " + " ".join(f"{v:6d}" for v in (w[b, 0] - w[b, 1]))
+                             + f"\n       G-start " + " ".join(f"{v:6d}" for v in (w[b, 2] - t0))
+                             + f"\n       G-end   " + " ".join(f"{v:6d}" for v in (w[b, 3] - t0))
+                             + f"\n       G len   " + " ".join(f"{v:6d}" for v in (w[b, 3] - w[b, 2])))
             e.close()
         print(line, flush=True)
