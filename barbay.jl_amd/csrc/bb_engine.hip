@@ -469,7 +469,9 @@ static bool try_resident(bb_handle* h) {
         NBL = std::max(1, (int)(NB * (pct / 100.0)));
         const long long rest = nbar - 8ll * NBL;
         nblk = 8 + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
-        if (nblk > h->nblk + (nb_fixed ? 8 : 0)) { NB = h->NB; NBL = 0; nblk = h->nblk; }   // (rounding pushed it over the grid that fits: stay uniform)
+        const long long p_uni = (br_tile_span(h->M, h->NB, true) + h->nthr - 1) / h->nthr, p_new = (br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr;
+        // stay uniform where rounding pushed the map over the grid that fits, or the slightly larger tiles need another pair slot
+        if (nblk > h->nblk + (nb_fixed ? 8 : 0) || p_new > p_uni) { NB = h->NB; NBL = 0; nblk = h->nblk; }
     }
     const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
     if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
