@@ -43,6 +43,12 @@ BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return __umulhi(a, b); }
 #else
 #define BB_STAMP(cx, S, i) ((void)0)
 #endif
+// wall-clock stamp (s_memrealtime: one 100 MHz counter for the whole device -- s_memtime counters are not comparable across CUs)
+#if defined(BB_STAMPS) && !defined(BB_EMU)
+#define BB_STAMP_RT(cx, S, i) do { if (threadIdx.x == 0) (S).stamps[(long long)(cx).block * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BB_STAMP_RT(cx, S, i) ((void)0)
+#endif
 // wave-0 timeline stamp after draining this wave's outstanding memory operations
 #if defined(BB_STAMPS) && !defined(BB_EMU)
 #define BB_STAMP_W(cx, S, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) (S).stamps[(long long)(cx).block * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)

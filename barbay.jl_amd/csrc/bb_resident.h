@@ -495,6 +495,7 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
     }
     bb_drain_and_meet(cx);           // every storing wave has drained its write-through stores
     BB_STAMP(cx, S, 24);
+    BB_STAMP_RT(cx, S, 29);
     BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
 }
 
@@ -531,6 +532,7 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     BB_STAMP(cx, S, 25);
+    BB_STAMP_RT(cx, S, 30);
     BB_PASS(cx, tid) {
         for (int j = tid; j < M.Ttot; j += cx.nthr) {
             int r = 0;
@@ -733,6 +735,8 @@ BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, con
 template <bool XG>
 BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, unsigned long long step, int* ok_slot) {
     const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
+    // (fetching the members' rows in one round trip -- two waves, 16 members each, partial sums through LDS -- measured SLOWER,
+    //  as round 1 had found for k_persist: 7.6 k cycles against 4.8 k for the leader's read + sum + publish)
     if (cx.block < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
 }
 template <int KIND, int P, bool XG>

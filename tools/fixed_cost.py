@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Diagnostic: fixed cost of a bb_run (kernel prologue / epilogue + host) -- kernel time (HIP events) and wall time for n steps."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import barbay_jl_amd as bb
+from barbay_jl_amd import synth
+wl = synth.fitness_normal(50000, 8, 42)
+e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42)
+e.run(1200)
+for n in (1, 2, 5, 10, 20, 40, 80):
+    ks, ws = [], []
+    for rep in range(7):
+        t0 = time.perf_counter(); e.run(n); ws.append((time.perf_counter() - t0) * 1e6); ks.append(e.stats()["last_run_ms"] * 1e3)
+    print(f"n {n:3d}: kernel {np.median(ks):8.1f} us  wall {np.median(ws):8.1f} us   per step {np.median(ks) / n:7.2f} / {np.median(ws) / n:7.2f}")

@@ -52,11 +52,13 @@ for rep in range(2):
             line += (f"\n     leaders: publish->members seen {np.median(s[lead, 17] - s[lead, 24]):.0f}, read+sum+store+flag {np.median(s[lead, 18] - s[lead, 17]):.0f}, "
                      f"then until group rows seen {np.median(s[lead, 1] - s[lead, 18]):.0f}; others: publish->group rows seen {np.median(s[~lead, 1] - s[~lead, 24]):.0f}, "
                      f"rows read+sum {np.median(s[:, 25] - s[:, 1]):.0f}; leaders publish earlier than others by {np.median(s[~lead, 24]) - np.median(s[lead, 24]):.0f}")
-            # (s_memtime counters differ between XCDs: compare tiles of one XCD only -- tiles b = 3 mod 8 under round-robin placement)
-            grp = np.arange(3, s.shape[0], 8)
-            for ev, nm in ((24, "publish"), (25, "rows seen+read"), (28, "G end")):
-                tt = s[grp, ev] - s[grp, ev].min()
-                line += f"\n     {nm:15s} spread over the tiles = 3 mod 8 (after the first): median {np.median(tt):.0f} p90 {np.percentile(tt, 90):.0f} max {tt.max()} (tile {grp[int(np.argmax(tt))]}); leader tile 3: {tt[0]}"
+            # wall-clock stamps (100 MHz): publish and totals-seen over all tiles, in shader cycles at ~2.4 GHz
+            for ev, nm in ((29, "publish"), (30, "totals seen")):
+                tt = (s[:, ev] - s[:, ev].min()) * 24
+                order = np.argsort(tt)
+                line += (f"\n     {nm:12s} (wall clock, cycles after the first tile): median {np.median(tt):.0f} p90 {np.percentile(tt, 90):.0f} max {tt.max()}; "
+                         f"last tiles {order[-5:].tolist()}; leaders {tt[:8].tolist()}")
+            line += f"\n     publish(last tile) -> totals seen(first / median / last tile): {(s[:, 30].min() - s[:, 29].max()) * 24} / {(np.median(s[:, 30]) - s[:, 29].max()) * 24:.0f} / {(s[:, 30].max() - s[:, 29].max()) * 24}"
             if os.environ.get("WAVES"):
                 w = e.stamps(per_wave=True).astype(np.int64)
                 for b in [int(x) for x in os.environ["WAVES"].split(",")]:
