@@ -54,6 +54,7 @@ class bb_advi_opts(C.Structure):
         ("window", C.c_int32), ("resum_every", C.c_int32), ("pre", C.c_double), ("post", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("steps_per_graph", C.c_int32), ("elbo_every", C.c_int32), ("launch_mode", C.c_int32),
+        ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32)),
     ]
 
 
@@ -163,7 +164,8 @@ class Engine:
                  samples_per_step: int = 1, optimizer: str = "TruncatedADAGrad", eta: float = 0.1,
                  tau: float = 40.0, window: int = 100, resum_every: int = 0, pre: float = 1.0,
                  post: float = 0.9, seed: int = 0, device: int = 0, rank: int = 0, world_size: int = 1,
-                 steps_per_graph: int = 0, elbo_every: int = 0, launch_mode: int = 0, ragged_method: bool = False, _lib: Optional[C.CDLL] = None):
+                 steps_per_graph: int = 0, elbo_every: int = 0, launch_mode: int = 0, ragged_method: bool = False,
+                 n_devices: int = 1, device_ids: Optional[Sequence[int]] = None, _lib: Optional[C.CDLL] = None):
         self._lib = _lib if _lib is not None else load_library()
         self._h = C.c_void_p()
         self.kind = kind
@@ -214,6 +216,11 @@ class Engine:
         o.eta, o.tau, o.window, o.resum_every, o.pre, o.post = eta, tau, window, resum_every, pre, post
         o.seed, o.device, o.rank, o.world_size = seed, device, rank, world_size
         o.steps_per_graph, o.elbo_every, o.launch_mode = steps_per_graph, elbo_every, launch_mode
+        if device_ids is not None:
+            n_devices = len(device_ids)
+            ids = hold(np.ascontiguousarray(device_ids, dtype=np.int32))
+            o.device_ids = _ptr(ids, C.POINTER(C.c_int32))
+        o.n_devices = int(n_devices)
         self._check(self._lib.bb_create(C.byref(md), C.byref(o), C.byref(self._h)))
         self.D = int(self._lib.bb_num_latents(self._h))
         self.samples_per_step = samples_per_step

@@ -258,6 +258,10 @@ struct bb_handle {
     DevState* dS = nullptr;
     BBLds* dL = nullptr;               // ... and of the resident launch's LDS carve-up (host copy: Lp)
     BBLds Lp{};
+    // single-process multi-device handle (bb_advi_opts.n_devices > 1): all the work is in the shards, one per device
+    std::vector<bb_handle*> shards;
+    bool group_resident = false;       // the shards run resident launches with in-process peer-mapped inboxes
+    bool in_group = false;             // this handle is a shard of a group: its peers' inboxes are plain pointers, not IPC mappings
     bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
     bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
 };
@@ -288,6 +292,8 @@ extern "C" void bb_default_opts(bb_advi_opts* o) {
     o->world_size = 1;
     o->steps_per_graph = 0;
     o->elbo_every = 0;
+    o->n_devices = 1;
+    o->device_ids = nullptr;
 }
 
 static void add_block(bb_handle* h, const char* name, int kind, long long n, long long* off) {
@@ -343,6 +349,7 @@ static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean,
 }
 
 struct bb_handle;
+static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
 static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
 #ifndef BB_EMU
 static int launch_check();
@@ -779,6 +786,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD && opts->window < 1) return bb_fail(BB_ERR_INVALID, "window must be >= 1");
     if (opts->world_size < 1 || opts->rank < 0 || opts->rank >= opts->world_size)
         return bb_fail(BB_ERR_INVALID, "bad rank/world_size %d/%d", opts->rank, opts->world_size);
+    if (opts->n_devices > 1) return group_create(md, opts, out);
 
     bb_handle* h = new bb_handle();
     h->o = *opts;
@@ -1063,8 +1071,10 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
 }
 
 static void p2p_release(bb_handle* h);
+static void group_destroy(bb_handle* g);
 extern "C" void bb_destroy(bb_handle* h) {
     if (!h) return;
+    if (!h->shards.empty()) { group_destroy(h); return; }
     BB_ENTER(h);
 #ifndef BB_EMU
     (void)hipStreamSynchronize(h->stream);
@@ -1282,8 +1292,183 @@ static int reset_optimizer(bb_handle* h) {
     return set_step(h, 0);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// single-process multi-device handle (bb_advi_opts.n_devices > 1; SURVEY.md 8b: "multi-GPU is driven inside the library by
+// one host thread").  The group handle owns one shard handle per device (rank i of n on device_ids[i]); their inboxes are wired
+// in process (hipDeviceEnablePeerAccess + plain pointers, no IPC), the resident launches of all shards are enqueued before any
+// is waited for.  Where the resident launch is not possible (a shard refuses: genotype model, S > 1, ELBO recording ...) the
+// group falls back to the split-phase step with the K moments summed on the host -- correct everywhere, slow.
+// ------------------------------------------------------------------------------------------------
+static int p2p_alloc_inbox(bb_handle* h);
+static int p2p_wire(bb_handle* h, void* const* bases);
+static int p2p_probe_launch(bb_handle* h, unsigned** res);
+static int p2p_probe_collect(bb_handle* h, unsigned* res, int32_t* ok);
+static int run_enqueue(bb_handle* h, int64_t n_steps);
+static int run_finish(bb_handle* h);
+static void owned_ranges(const bb_handle* sh, std::vector<std::pair<long long, long long>>& out) {
+    const DevModel& M = sh->M;
+    const long long b_lo = sh->b_lo, b_hi = sh->b_hi;
+    const long long m_lo = std::max(b_lo, M.nn) - M.nn, m_hi = std::max(b_hi, M.nn) - M.nn;
+    for (int r = 0; r < M.R; ++r) out.push_back({M.off_l[r] + b_lo * M.T[r], M.off_l[r] + b_hi * M.T[r]});
+    if (m_hi <= m_lo) return;
+    if (M.kind == BB_MODEL_FITNESS || M.kind == BB_MODEL_MULTIENV) {
+        out.push_back({M.blk_lo[BK_S] + m_lo * M.E, M.blk_lo[BK_S] + m_hi * M.E});
+        out.push_back({M.blk_lo[BK_LS] + m_lo * M.E, M.blk_lo[BK_LS] + m_hi * M.E});
+    } else if (M.kind == BB_MODEL_GENOTYPE) {      // (theta is per genotype: replicated, taken from shard 0)
+        for (int k : {BK_TT, BK_LT, BK_LS}) out.push_back({M.blk_lo[k] + m_lo, M.blk_lo[k] + m_hi});
+    } else {
+        const long long E_ = M.kind == BB_MODEL_MULTIENV_REPLICATE ? M.E : 1;
+        out.push_back({M.blk_lo[BK_S] + m_lo * E_, M.blk_lo[BK_S] + m_hi * E_});
+        for (int r = 0; r < M.R; ++r)
+            for (int k : {BK_TT, BK_LT, BK_LS}) out.push_back({M.blk_lo[k] + (r * M.nb + m_lo) * E_, M.blk_lo[k] + (r * M.nb + m_hi) * E_});
+    }
+}
+
+static void group_destroy(bb_handle* g) {
+    for (bb_handle* sh : g->shards) bb_destroy(sh);
+    g->shards.clear();
+    delete g;
+}
+
+static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
+    const int n = opts->n_devices;
+    if (n > BB_MAX_WORLD) return bb_fail(BB_ERR_UNSUPPORTED, "at most %d devices per handle", BB_MAX_WORLD);
+    if (opts->world_size != 1 || opts->rank != 0) return bb_fail(BB_ERR_INVALID, "n_devices > 1 needs rank 0 / world_size 1 (the handle shards by itself)");
+    bb_handle* g = new bb_handle();
+    g->o = *opts;
+    g->o.device = opts->device_ids ? opts->device_ids[0] : 0;
+    int rc = 0;
+    for (int i = 0; i < n && !rc; ++i) {
+        bb_advi_opts o = *opts;
+        o.n_devices = 1;
+        o.device_ids = nullptr;
+        o.device = opts->device_ids ? opts->device_ids[i] : i;
+        o.rank = i;
+        o.world_size = n;
+        bb_handle* sh = nullptr;
+        rc = bb_create(md, &o, &sh);
+        if (!rc) { sh->in_group = true; g->shards.push_back(sh); }
+    }
+    if (rc) { group_destroy(g); return rc; }
+    g->M = g->shards[0]->M;                      // (host-side copies of shapes and block ranges; the device pointers inside are shard 0's)
+    g->blocks = g->shards[0]->blocks;
+    g->b_lo = 0;
+    g->b_hi = g->M.B;
+    // resident launches with in-process peer-mapped inboxes, if every shard can (and the caller did not ask for two kernels)
+    bool ok = opts->launch_mode != 1 && md->kind != BB_MODEL_GENOTYPE;
+#ifndef BB_EMU
+    for (int i = 0; i < n && ok; ++i)
+        for (int j = 0; j < n && ok; ++j) {
+            const int di = g->shards[i]->o.device, dj = g->shards[j]->o.device;
+            if (di == dj) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) { ok = false; break; }
+            DevGuard guard(di);
+            hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+            (void)hipGetLastError();
+        }
+#endif
+    void* bases[BB_MAX_WORLD] = {};
+    for (int i = 0; i < n && ok; ++i) {
+        BB_ENTER(g->shards[i]);
+        ok = p2p_alloc_inbox(g->shards[i]) == BB_OK;
+        bases[i] = g->shards[i]->p2p_inbox;
+    }
+    for (int i = 0; i < n && ok; ++i) { BB_ENTER(g->shards[i]); ok = p2p_wire(g->shards[i], bases) == BB_OK; }
+    if (ok) {                                    // transport probe: all devices at once
+        unsigned* res[BB_MAX_WORLD] = {};
+        for (int i = 0; i < n; ++i) { BB_ENTER(g->shards[i]); if (p2p_probe_launch(g->shards[i], &res[i]) != BB_OK) ok = false; }
+        for (int i = 0; i < n; ++i) {
+            BB_ENTER(g->shards[i]);
+            int32_t good = 0;
+            if (p2p_probe_collect(g->shards[i], res[i], &good) != BB_OK || !good) ok = false;
+        }
+    }
+    if (ok) for (int i = 0; i < n && ok; ++i) ok = bb_p2p_enable(g->shards[i], 1) == BB_OK;
+    if (!ok) for (bb_handle* sh : g->shards) if (sh->p2p_ready) (void)bb_p2p_enable(sh, 0);
+    g->group_resident = ok;
+    if (!ok && opts->launch_mode == 2) { group_destroy(g); return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2: the shards cannot run resident launches with peer-mapped inboxes: %s", g_err); }
+    *out = g;
+    return BB_OK;
+}
+
+static int group_run(bb_handle* g, int64_t n_steps) {
+    int rc = 0;
+    if (g->group_resident) {
+#ifdef BB_EMU
+        for (bb_handle* sh : g->shards) sh->req_steps += n_steps;
+        rc = emu_run_group(g->shards.data(), (int)g->shards.size(), n_steps);      // the emulation steps the shards in lock step
+        g->step = g->shards[0]->step;
+        return rc;
+#endif
+        for (bb_handle* sh : g->shards) { BB_ENTER(sh); if ((rc = run_enqueue(sh, n_steps))) break; }
+        int rc2 = 0;                              // (wait for whatever was launched, also after an error)
+        for (bb_handle* sh : g->shards) { BB_ENTER(sh); const int r = run_finish(sh); if (r && !rc2) rc2 = r; }
+        if (!rc) rc = rc2;
+    } else {
+        // the two-kernel step of every shard with the exchanges (K moments; per-genotype gradient sums of the genotype model)
+        // summed on the host: enqueue_step with host reductions in place of the RCCL all-reduces
+        const int S = g->o.samples_per_step < 1 ? 1 : g->o.samples_per_step;
+        const size_t K = (size_t)g->shards[0]->M.K, G = (size_t)g->shards[0]->M.G;
+        const bool geno = g->shards[0]->M.kind == BB_MODEL_GENOTYPE;
+        std::vector<double> part(std::max(K, G)), total(std::max(K, G));
+        auto exchange = [&](size_t n, double* DevState::*buf) -> int {
+            std::fill(total.begin(), total.begin() + n, 0.0);
+            for (bb_handle* sh : g->shards) {
+                BB_ENTER(sh);
+                int r = d2h(part.data(), sh->S.*buf, n * 8, sh->stream);
+                if (r) return r;
+                for (size_t k = 0; k < n; ++k) total[k] += part[k];
+            }
+            for (bb_handle* sh : g->shards) { BB_ENTER(sh); int r = h2d(sh->S.*buf, total.data(), n * 8, sh->stream); if (r) return r; }
+            return 0;
+        };
+        for (int64_t it = 0; it < n_steps && !rc; ++it) {
+            for (int smp = 0; smp < S && !rc; ++smp) {
+                std::vector<RunArgs> As;
+                for (bb_handle* sh : g->shards) As.push_back(make_args(sh, sh->step, smp, S, true, elbo_wanted(sh, sh->step)));
+                for (size_t i = 0; i < g->shards.size() && !rc; ++i) { BB_ENTER(g->shards[i]); rc = sample_half(g->shards[i], As[i]); }
+                if (!rc) rc = exchange(K, &DevState::totals);
+                for (size_t i = 0; i < g->shards.size() && !rc; ++i) {
+                    BB_ENTER(g->shards[i]);
+                    rc = launch_update(g->shards[i], As[i]);
+                    if (!rc && geno) rc = launch_geno_sum(g->shards[i]);
+                }
+                if (!rc && geno) rc = exchange(G, &DevState::gsum);
+                for (size_t i = 0; i < g->shards.size() && !rc && geno; ++i) { BB_ENTER(g->shards[i]); rc = launch_geno(g->shards[i], As[i], 1, 0, As[i].par); }
+            }
+            for (bb_handle* sh : g->shards) sh->step++;
+        }
+        for (bb_handle* sh : g->shards) { BB_ENTER(sh); const int r = dsync(sh->stream); if (r && !rc) rc = r; }
+    }
+    g->step = g->shards[0]->step;
+    return rc;
+}
+
+static int group_get_params(bb_handle* g, double* mu, double* omega) {
+    const size_t D = (size_t)g->M.D;
+    std::vector<double> tm(D), to(D);
+    int rc = bb_get_params(g->shards[0], mu, omega);      // replicated blocks (and its own shard) from shard 0
+    for (size_t i = 1; i < g->shards.size() && !rc; ++i) {
+        if ((rc = bb_get_params(g->shards[i], tm.data(), to.data()))) break;
+        std::vector<std::pair<long long, long long>> rg;
+        owned_ranges(g->shards[i], rg);
+        for (auto& r : rg) {
+            std::copy(tm.begin() + r.first, tm.begin() + r.second, mu + r.first);
+            std::copy(to.begin() + r.first, to.begin() + r.second, omega + r.first);
+        }
+    }
+    return rc;
+}
+
+#define BB_GROUP_UNSUPPORTED(h, what) \
+    do { if (!(h)->shards.empty()) return bb_fail(BB_ERR_UNSUPPORTED, what " is not available on a multi-device handle (n_devices > 1)"); } while (0)
+
 extern "C" int bb_init_meanfield(bb_handle* h) {
     if (!h) return bb_fail(BB_ERR_INVALID, "null handle");
+    if (!h->shards.empty()) { int rc = 0; for (bb_handle* sh : h->shards) if (!rc) rc = bb_init_meanfield(sh); h->step = 0; return rc; }
     BB_ENTER(h);
     const int nb = (int)std::min<long long>(((h->M.D + 1) / 2 + 255) / 256, 1024);
 #ifdef BB_EMU
@@ -1298,6 +1483,7 @@ extern "C" int bb_init_meanfield(bb_handle* h) {
 
 extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega) {
     if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->shards.empty()) { int rc = 0; for (bb_handle* sh : h->shards) if (!rc) rc = bb_set_params(sh, mu, omega); h->step = 0; return rc; }
     BB_ENTER(h);
     int rc;
     if ((rc = h2d(h->S.mu, mu, (size_t)h->M.D * 8, h->stream))) return rc;
@@ -1307,6 +1493,7 @@ extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega
 
 extern "C" int bb_get_params(bb_handle* h, double* mu, double* omega) {
     if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->shards.empty()) return group_get_params(h, mu, omega);
     BB_ENTER(h);
     int rc;
     if ((rc = dsync(h->stream))) return rc;
@@ -1349,9 +1536,8 @@ static int build_graph(bb_handle* h, int steps) {
 }
 #endif
 
-extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
-    if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
-    BB_ENTER(h);
+// bb_run in two halves (a multi-device handle enqueues on all its shards before it waits for any)
+static int run_enqueue(bb_handle* h, int64_t n_steps) {
     if (h->sample != 0) return bb_fail(BB_ERR_INVALID, "a split-phase step is in flight");
     int rc = 0;
     int64_t done = 0;
@@ -1394,17 +1580,31 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     }
 #ifndef BB_EMU
     BB_HIP(hipEventRecord(h->ev1, h->stream));
+#endif
+    return BB_OK;
+}
+static int run_finish(bb_handle* h) {
+#ifndef BB_EMU
     BB_HIP(hipStreamSynchronize(h->stream));
     float ms = 0;
     BB_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_run_ms = ms;
 #endif
-    if ((rc = check_persistent(h))) return rc;
-    return BB_OK;
+    return check_persistent(h);
+}
+
+extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
+    if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (!h->shards.empty()) return group_run(h, n_steps);
+    BB_ENTER(h);
+    int rc = run_enqueue(h, n_steps);
+    if (rc) return rc;
+    return run_finish(h);
 }
 
 extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
     if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_run_profiled");
     BB_ENTER(h);
 #ifdef BB_EMU
     return bb_run(h, n_steps);
@@ -1445,6 +1645,7 @@ extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
 extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps, int32_t S,
                             double* elbo, double* grad_mu, double* grad_omega) {
     if (!h || !mu || !omega || S < 1) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_elbo_grad");
     BB_ENTER(h);
     if (h->o.world_size > 1 && !eps) return bb_fail(BB_ERR_UNSUPPORTED, "bb_elbo_grad on a sharded handle needs explicit eps");
     const size_t D = (size_t)h->M.D;
@@ -1519,6 +1720,7 @@ extern "C" int bb_logdensity_grad(bb_handle* h, const double* z, double* logp, d
 
 extern "C" int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out) {
     if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_get_elbo_trace");
     BB_ENTER(h);
     if (h->o.elbo_every <= 0) return bb_fail(BB_ERR_INVALID, "ELBO recording is off (elbo_every = 0)");
     std::vector<double> ring(BB_ELBO_RING);
@@ -1538,6 +1740,7 @@ extern "C" int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, do
 
 extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, int64_t hi, double* out) {
     if (!h || !out || lo < 0 || hi < lo) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (!h->shards.empty()) return bb_debug_normals(h->shards[0], step, stream, lo, hi, out);
     BB_ENTER(h);
     const size_t n = (size_t)(hi - lo);
     if (n == 0) return BB_OK;
@@ -1563,6 +1766,7 @@ extern "C" int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int
 
 extern "C" int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n) {
     if (!h || !out) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (!h->shards.empty()) return bb_debug_stamps(h->shards[0], out, n);
     if (n < 0) { out[0] = (uint64_t)(h->nblk + 8); return BB_OK; }     // rows of the block-stamp area (the per-wave area follows it)
     BB_ENTER(h);
     const int64_t have = (int64_t)(h->nblk + 8) * (32 + 64);
@@ -1584,7 +1788,7 @@ static size_t p2p_probe_words_off(const bb_handle* h) { return (size_t)32 * 2 * 
 static void p2p_release(bb_handle* h) {
 #ifndef BB_EMU
     for (int r = 0; r < BB_MAX_WORLD; ++r)
-        if (h->p2p_peer[r] && r != h->o.rank) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
+        if (h->p2p_peer[r] && r != h->o.rank && !h->in_group) (void)hipIpcCloseMemHandle(h->p2p_peer[r]);
     if (h->p2p_inbox) (void)hipFree(h->p2p_inbox);
 #else
     if (h->p2p_inbox) free(h->p2p_inbox);
@@ -1593,26 +1797,44 @@ static void p2p_release(bb_handle* h) {
     h->p2p_ready = h->p2p_on = false;
 }
 
-extern "C" int bb_p2p_export(bb_handle* h, void* handle_out) {
-    if (!h || !handle_out) return bb_fail(BB_ERR_INVALID, "null argument");
-    BB_ENTER(h);
-    if (h->o.world_size < 2) return bb_fail(BB_ERR_INVALID, "bb_p2p_export needs a sharded handle (world_size > 1)");
+// this rank's inbox: fine-grained device memory (remote stores and local polls must meet in memory, not in either side's L2)
+static int p2p_alloc_inbox(bb_handle* h) {
+    if (h->o.world_size < 2) return bb_fail(BB_ERR_INVALID, "the cross-GPU leg needs a sharded handle (world_size > 1)");
     if (h->o.world_size > BB_MAX_WORLD) return bb_fail(BB_ERR_UNSUPPORTED, "at most %d ranks", BB_MAX_WORLD);
     if (h->M.kind == BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_UNSUPPORTED, "the genotype model has no resident launch");
-    memset(handle_out, 0, BB_P2P_HANDLE_BYTES);
-    if (!h->p2p_inbox) {
-        h->p2p_rows_bytes = p2p_rows_bytes(h);
-        h->p2p_bytes = h->p2p_rows_bytes + (p2p_probe_words_off(h) + (size_t)32 * h->o.world_size) * 4;
+    if (h->p2p_inbox) return BB_OK;
+    h->p2p_rows_bytes = p2p_rows_bytes(h);
+    h->p2p_bytes = h->p2p_rows_bytes + (p2p_probe_words_off(h) + (size_t)32 * h->o.world_size) * 4;
 #ifdef BB_EMU
-        h->p2p_inbox = calloc(1, h->p2p_bytes);
-        if (!h->p2p_inbox) return bb_fail(BB_ERR_DEVICE, "out of memory");
+    h->p2p_inbox = calloc(1, h->p2p_bytes);
+    if (!h->p2p_inbox) return bb_fail(BB_ERR_DEVICE, "out of memory");
 #else
-        // fine-grained: remote stores and local polls must meet in memory, not in either side's L2
-        BB_HIP(hipExtMallocWithFlags(&h->p2p_inbox, h->p2p_bytes, hipDeviceMallocFinegrained));
-        BB_HIP(hipMemsetAsync(h->p2p_inbox, 0, h->p2p_bytes, h->stream));
-        BB_HIP(hipStreamSynchronize(h->stream));
+    BB_HIP(hipExtMallocWithFlags(&h->p2p_inbox, h->p2p_bytes, hipDeviceMallocFinegrained));
+    BB_HIP(hipMemsetAsync(h->p2p_inbox, 0, h->p2p_bytes, h->stream));
+    BB_HIP(hipStreamSynchronize(h->stream));
 #endif
+    return BB_OK;
+}
+
+// every rank's inbox as seen from this rank (bases[own rank] = the local inbox)
+static int p2p_wire(bb_handle* h, void* const* bases) {
+    for (int r = 0; r < h->o.world_size; ++r) {
+        if (!bases[r]) return bb_fail(BB_ERR_COMM, "rank %d's inbox did not map", r);
+        h->p2p_peer[r] = bases[r];
+        h->S.xout[r] = (double*)bases[r];
+        h->S.xout_rdy[r] = (unsigned*)((char*)bases[r] + h->p2p_rows_bytes);
     }
+    h->p2p_ready = true;
+    return sync_descriptors(h);
+}
+
+extern "C" int bb_p2p_export(bb_handle* h, void* handle_out) {
+    if (!h || !handle_out) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->shards.empty()) return bb_fail(BB_ERR_UNSUPPORTED, "a multi-device handle wires its shards itself");
+    BB_ENTER(h);
+    memset(handle_out, 0, BB_P2P_HANDLE_BYTES);
+    int rc = p2p_alloc_inbox(h);
+    if (rc) return rc;
 #ifdef BB_EMU
     memcpy(handle_out, &h->p2p_inbox, sizeof(void*));
 #else
@@ -1626,9 +1848,11 @@ extern "C" int bb_p2p_export(bb_handle* h, void* handle_out) {
 
 extern "C" int bb_p2p_import(bb_handle* h, const void* handles) {
     if (!h || !handles) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->shards.empty()) return bb_fail(BB_ERR_UNSUPPORTED, "a multi-device handle wires its shards itself");
     BB_ENTER(h);
     if (!h->p2p_inbox) return bb_fail(BB_ERR_INVALID, "bb_p2p_export comes first");
     const int W = h->o.world_size;
+    void* bases[BB_MAX_WORLD] = {};
     for (int r = 0; r < W; ++r) {
         void* base = nullptr;
         if (r == h->o.rank) base = h->p2p_inbox;
@@ -1643,24 +1867,39 @@ extern "C" int bb_p2p_import(bb_handle* h, const void* handles) {
                 BB_HIP(hipIpcOpenMemHandle(&base, hnd, hipIpcMemLazyEnablePeerAccess));
             } else base = h->p2p_peer[r];
 #endif
-            if (!base) return bb_fail(BB_ERR_COMM, "rank %d's inbox did not map", r);
         }
-        h->p2p_peer[r] = base;
-        h->S.xout[r] = (double*)base;
-        h->S.xout_rdy[r] = (unsigned*)((char*)base + h->p2p_rows_bytes);
+        bases[r] = base;
     }
-    h->p2p_ready = true;
-    return sync_descriptors(h);
+    return p2p_wire(h, bases);
 }
 
-extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
-    if (!h || !ok) return bb_fail(BB_ERR_INVALID, "null argument");
-    BB_ENTER(h);
-    *ok = 0;
-    if (!h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
-    const int W = h->o.world_size;
+static void dfree_probe(unsigned* res) {
+#ifndef BB_EMU
+    if (res) (void)hipFree(res);
+#else
+    (void)res;
+#endif
+}
+
+// transport probe in two halves, so that one host thread can run it on several devices at once: every rank's kernel waits for
+// the tokens of all the others
+static int p2p_probe_launch(bb_handle* h, unsigned** res) {
+    *res = nullptr;
     ++h->p2p_seq;
+#ifndef BB_EMU
+    BB_HIP(hipMalloc((void**)res, 64 * 4));
+    BB_HIP(hipMemsetAsync(*res, 0, 64 * 4, h->stream));
+    hipLaunchKernelGGL(k_p2p_probe_seq, dim3(1), dim3(64), 0, h->stream, h->S, h->o.rank, h->o.world_size, p2p_probe_words_off(h), h->p2p_seq, *res);
+    return launch_check();
+#else
+    return BB_OK;
+#endif
+}
+static int p2p_probe_collect(bb_handle* h, unsigned* res, int32_t* ok) {
+    const int W = h->o.world_size;
+    *ok = 0;
 #ifdef BB_EMU
+    (void)res;
     // single address space: the "transport" is a pointer; check that every rank's inbox is distinct and writable
     for (int r = 0; r < W; ++r) {
         if (!h->S.xout_rdy[r]) return BB_OK;
@@ -1669,15 +1908,8 @@ extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
     *ok = 1;
     return BB_OK;
 #else
-    // Every rank's token carries the same sequence number only if all ranks call this the same number of times
-    // (they do: the caller votes on the outcome), so a peer's token is predictable: replace the low byte.
-    unsigned* res = nullptr;
-    BB_HIP(hipMalloc((void**)&res, 64 * 4));
-    BB_HIP(hipMemsetAsync(res, 0, 64 * 4, h->stream));
-    hipLaunchKernelGGL(k_p2p_probe_seq, dim3(1), dim3(64), 0, h->stream, h->S, h->o.rank, W, p2p_probe_words_off(h), h->p2p_seq, res);
-    int rc = launch_check();
     unsigned host[64] = {0};
-    if (!rc) rc = d2h(host, res, sizeof host, h->stream);
+    int rc = d2h(host, res, sizeof host, h->stream);
     (void)hipFree(res);
     if (rc) return rc;
     int good = 1;
@@ -1687,8 +1919,23 @@ extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
 #endif
 }
 
+extern "C" int bb_p2p_selftest(bb_handle* h, int32_t* ok) {
+    if (!h || !ok) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->shards.empty()) return bb_fail(BB_ERR_UNSUPPORTED, "a multi-device handle wires its shards itself");
+    BB_ENTER(h);
+    *ok = 0;
+    if (!h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
+    // Every rank's token carries the same sequence number only if all ranks call this the same number of times
+    // (they do: the caller votes on the outcome), so a peer's token is predictable: replace the low byte.
+    unsigned* res = nullptr;
+    int rc = p2p_probe_launch(h, &res);
+    if (rc) { dfree_probe(res); return rc; }
+    return p2p_probe_collect(h, res, ok);
+}
+
 extern "C" int bb_p2p_enable(bb_handle* h, int32_t on) {
     if (!h) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_p2p_enable");
     BB_ENTER(h);
     if (on && !h->p2p_ready) return bb_fail(BB_ERR_INVALID, "bb_p2p_import comes first");
     h->p2p_on = on != 0;
@@ -1725,6 +1972,22 @@ extern "C" int64_t bb_hier_units(const bb_handle* h) {
 
 extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* stdv) {
     if (!h || !median || !stdv) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (!h->shards.empty()) {
+        // the whole posterior onto shard 0 (entries it does not own are dead weight there: never read by its tiles), then its sampler
+        bb_handle* s0 = h->shards[0];
+        const size_t D = (size_t)h->M.D;
+        std::vector<double> mu(D), om(D);
+        int rc = group_get_params(h, mu.data(), om.data());
+        BB_ENTER(s0);
+        if (!rc) rc = h2d(s0->S.mu, mu.data(), D * 8, s0->stream);
+        if (!rc) rc = h2d(s0->S.om, om.data(), D * 8, s0->stream);
+        if (rc) return rc;
+        const int ws = s0->o.world_size;
+        s0->o.world_size = 1;
+        rc = bb_hier_fitness(s0, n_samples, seed, median, stdv);
+        s0->o.world_size = ws;
+        return rc;
+    }
     BB_ENTER(h);
     if (h->M.kind < BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_INVALID, "bb_hier_fitness applies to the hierarchical models only");
     if (n_samples < 2 || n_samples > 16384) return bb_fail(BB_ERR_UNSUPPORTED, "n_samples must be in 2..16384");
@@ -1771,6 +2034,21 @@ extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, d
 extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     if (!h || !s) return bb_fail(BB_ERR_INVALID, "null argument");
     BB_ENTER(h);
+    if (!h->shards.empty()) {       // shard 0's figures; what adds up over the shards is added up
+        int rc = bb_get_stats(h->shards[0], s);
+        for (size_t i = 1; i < h->shards.size() && !rc; ++i) {
+            bb_stats t;
+            if ((rc = bb_get_stats(h->shards[i], &t))) break;
+            s->bytes_per_step += t.bytes_per_step; s->bytes_sample += t.bytes_sample; s->bytes_update += t.bytes_update;
+            s->n_blocks += t.n_blocks;
+            s->last_run_ms = std::max(s->last_run_ms, t.last_run_ms);
+            s->persistent_pairs = std::min(s->persistent_pairs, t.persistent_pairs);
+            s->resident_kernel = std::min(s->resident_kernel, t.resident_kernel);
+        }
+        s->shard_lo = 0;
+        s->shard_hi = h->M.B;
+        return rc;
+    }
     memset(s, 0, sizeof *s);
     s->n_latents = h->M.D;
     s->n_moments = h->M.K;
@@ -1812,6 +2090,7 @@ extern "C" int bb_comm_make_id(void* id_out) {
 
 extern "C" int bb_comm_init(bb_handle* h, const void* id_in) {
     if (!h || !id_in) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_comm_init");
     BB_ENTER(h);
 #ifdef BB_EMU
     return bb_fail(BB_ERR_COMM, "no RCCL in the emulation build");
@@ -1829,6 +2108,7 @@ extern "C" int bb_comm_init(bb_handle* h, const void* id_in) {
 
 extern "C" int bb_step_moments(bb_handle* h, double* partial) {
     if (!h || !partial) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_step_moments");
     BB_ENTER(h);
     if (h->M.kind == BB_MODEL_GENOTYPE && h->o.world_size > 1)
         return bb_fail(BB_ERR_UNSUPPORTED, "split-phase stepping of the sharded genotype model needs a second exchange; use bb_comm_init + bb_run");
@@ -1845,6 +2125,7 @@ extern "C" int bb_step_moments(bb_handle* h, double* partial) {
 
 extern "C" int bb_step_apply(bb_handle* h, const double* total) {
     if (!h || !total) return bb_fail(BB_ERR_INVALID, "null argument");
+    BB_GROUP_UNSUPPORTED(h, "bb_step_apply");
     BB_ENTER(h);
     const int S = h->o.samples_per_step;
     RunArgs A = make_args(h, h->step, h->sample, S, true, elbo_wanted(h, h->step));

@@ -3,7 +3,8 @@
 
 Differences from the reference, all additive: `advi` / `opt` are the small dataclasses below instead of
 Turing types (`ADVI(samples_per_step, max_iters)`, `TruncatedADAGrad(eta, tau, n)`,
-`DecayedADAGrad(eta, pre, post)`, src/vi.jl:98-99), and `seed`, `device`, `engine_kwargs` select the
+`DecayedADAGrad(eta, pre, post)`, src/vi.jl:98-99), and `seed`, `device`, `engine_kwargs` (e.g. `n_devices=8`: one
+call, all GPUs of the node -- include/barbay_hip.h bb_advi_opts.n_devices) select the
 Philox key, the GPU and engine options.  Errors the reference raises with `error(...)` are `BarBayError`.
 """
 from __future__ import annotations

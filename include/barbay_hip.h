@@ -15,7 +15,7 @@
  *    needs during the call and never retains a host pointer.
  *  - the flat latent vector is the concatenation of the model's `~` blocks in
  *    source order with Julia column-major indexing.
- *  - one handle = one host thread at a time = one GPU.
+ *  - one handle = one host thread at a time; it drives one GPU, or bb_advi_opts.n_devices GPUs of the node.
  */
 #ifndef BARBAY_HIP_H
 #define BARBAY_HIP_H
@@ -114,6 +114,12 @@ typedef struct bb_advi_opts {
     int32_t launch_mode;      /* 0 = auto; 1 = two kernels per sample (graph / eager);
                                  2 = one resident launch with a grid barrier per step (S = 1,
                                  single GPU, no ELBO recording; error if not eligible)     */
+    int32_t n_devices;        /* > 1: ONE handle drives this many GPUs from the calling host
+                                 thread: the barcodes shard over the devices,
+                                 the resident launches run concurrently and exchange their
+                                 group rows through peer-mapped inboxes (xGMI); rank /
+                                 world_size must then be 0 / 1.  0 or 1 = one device.       */
+    const int32_t* device_ids;/* [n_devices] HIP ordinals, or NULL = 0 .. n_devices-1       */
 } bb_advi_opts;
 
 typedef struct bb_handle bb_handle;

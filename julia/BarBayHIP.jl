@@ -53,6 +53,8 @@ mutable struct bb_advi_opts
     steps_per_graph::Int32
     elbo_every::Int32
     launch_mode::Int32
+    n_devices::Int32
+    device_ids::Ptr{Int32}
     bb_advi_opts() = new()
 end
 
@@ -83,14 +85,14 @@ _prior_arrays(p::Matrix{Float64}) = (p[:, 1], p[:, 2])
 """
     vi(model_name, R, n_t, n_neutral, n_bc; samples_per_step, max_iters, optimizer, priors..., envs, genotypes, seed)
 
-Drop-in for `Turing.vi(bayes_model, advi; optimizer=opt)`.  `R` / `n_t` are `data_arrays.bc_count` /
+Drop-in for `Turing.vi(bayes_model, advi; optimizer=opt)`.  `devices = collect(0:7)` runs the one call on all GPUs of the node.  `R` / `n_t` are `data_arrays.bc_count` /
 `data_arrays.bc_total` exactly as `utils.data_to_arrays` returns them (Matrix, 3-D Array or Vector{Matrix}).
 """
 function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
             samples_per_step::Int=1, max_iters::Int=10_000,
             optimizer::Symbol=:TruncatedADAGrad, eta=0.1, tau=40.0, n=100, pre=1.0, post=0.9,
             priors::Dict{Symbol,<:Any}=Dict{Symbol,Any}(), envs=nothing, genotypes=nothing,
-            seed::Integer=0, device::Integer=0, hier_samples::Integer=10_000)
+            seed::Integer=0, device::Integer=0, devices::Vector{<:Integer}=Int[], hier_samples::Integer=10_000)
     mats = R isa Vector ? R : (ndims(R) == 3 ? [R[:, :, r] for r in axes(R, 3)] : [R])
     tots = n_t isa Vector{<:Vector} ? n_t : (ndims(n_t) == 2 ? [n_t[:, r] for r in axes(n_t, 2)] : [n_t])
     n_time = Int32[size(m, 1) for m in mats]
@@ -109,8 +111,16 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
     opts.optimizer = optimizer == :TruncatedADAGrad ? 0 : 1
     opts.eta, opts.tau, opts.window, opts.pre, opts.post = eta, tau, n, pre, post
     opts.seed, opts.device = seed, device
+    # devices = [0, 1, ..., 7]: this one call drives all of them (the barcodes shard over the devices inside the library,
+    # resident launches exchanging over xGMI); empty or one entry: a single GPU
+    dev_ids = Int32.(devices)
+    if length(dev_ids) > 1
+        opts.n_devices, opts.device_ids = length(dev_ids), pointer(dev_ids)
+    elseif length(dev_ids) == 1
+        opts.device = dev_ids[1]
+    end
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve n_time counts totals env_idx geno_idx pa begin
+    GC.@preserve n_time counts totals env_idx geno_idx pa dev_ids begin
         md = bb_model_desc(KIND[model_name], length(mats), n_neutral, n_bc, pointer(n_time), pointer(counts),
                            pointer(totals), isempty(env_idx) ? 0 : maximum(env_idx) + 1,
                            isempty(env_idx) ? C_NULL : pointer(env_idx),

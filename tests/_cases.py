@@ -313,3 +313,42 @@ def case_p2p_resident(lib, name, world, steps=7):
     finally:
         for e in es:
             e.close()
+
+
+def case_multi_device_handle(lib, name, n=2, steps=9, expect_resident=True, **ekw):
+    """bb_advi_opts.n_devices > 1: ONE handle, one host thread, n shards (here all on device 0) -- resident
+    launches with in-process peer-mapped inboxes; posterior, layout and stats as from a single-device handle."""
+    sp = synth(name, seed=4)
+    kw = dict(seed=5, window=4, resum_every=1)
+    with make_engine(sp, lib, launch_mode=1, **kw) as e1:
+        e1.run(steps)
+        m1, s1 = e1.posterior()
+        p1 = e1.get_params()
+        lay1 = e1.layout()
+    with make_engine(sp, lib, device_ids=[0] * n, **kw, **ekw) as e:
+        assert e.layout() == lay1 and e.D == sp.D
+        for _ in range(2):                      # the second pass restarts with the inboxes still holding the first's words
+            e.init_meanfield()
+            e.run(3)
+            e.run(steps - 3)
+        st = e.stats()
+        m, s = e.posterior()
+        mu, om = e.get_params()
+        assert st["steps_done"] == steps and (st["shard_lo"], st["shard_hi"]) == (0, sp.n_neutral + sp.n_bc)
+        assert (st["resident_kernel"] > 0) == bool(expect_resident), st
+        assert np.abs(m - m1).max() < 1e-9 and np.abs(s - s1).max() < 1e-9
+        assert np.abs(mu - p1[0]).max() < 1e-9 and np.abs(om - p1[1]).max() < 1e-9
+        if e.hier_units() > 0:                  # the derived-fitness sampler sees the whole posterior through the group handle
+            with make_engine(sp, lib, launch_mode=1, **kw) as eh:
+                eh.set_params(mu, om)
+                med1, sd1 = eh.hier_fitness(500, seed=3)
+            med, sd = e.hier_fitness(500, seed=3)
+            assert np.abs(med - med1).max() < 1e-12 and np.abs(sd - sd1).max() < 1e-12
+        # restart from explicit parameters on every shard
+        e.set_params(p1[0], p1[1])
+        e.run(2)
+        e1b = make_engine(sp, lib, launch_mode=1, **kw)
+        e1b.set_params(p1[0], p1[1])
+        e1b.run(2)
+        assert np.abs(e.get_params()[0] - e1b.get_params()[0]).max() < 1e-9
+        e1b.close()

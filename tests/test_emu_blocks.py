@@ -194,3 +194,19 @@ def test_running_window_survives_a_gradient_spike(emu_lib):
     for got, tol in zip(out[1:], (1e-9, 1e-6)):
         assert np.abs(got[0] - out[0][0]).max() < tol, np.abs(got[0] - out[0][0]).max()
         assert np.abs(got[1] - out[0][1]).max() < tol, np.abs(got[1] - out[0][1]).max()
+
+
+@pytest.mark.parametrize("name,n", [("fitness_multi_tile", 2), ("fitness_T6", 3), ("multienv_T8", 2), ("replicate_ragged", 2)])
+def test_multi_device_handle(emu_lib, monkeypatch, name, n):
+    """One handle, n shards in one process (bb_advi_opts.n_devices): the SURVEY.md 8b boundary the Julia drop-in calls."""
+    monkeypatch.setenv("BB_TUNE_NB", "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "256")
+    c.case_multi_device_handle(emu_lib, name, n)
+
+
+def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeypatch):
+    """Where a shard cannot run the resident launch (genotype model; S > 1) the group steps split-phase, moments summed on the host."""
+    monkeypatch.setenv("BB_TUNE_NB", "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "256")
+    c.case_multi_device_handle(emu_lib, "multienv", 2, expect_resident=False, launch_mode=1)
+    c.case_multi_device_handle(emu_lib, "genotype", 3, expect_resident=False)

@@ -216,3 +216,19 @@ def test_owner_computes_launch_geometries(hip_lib, monkeypatch, nb, nthr):
     monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
     c.case_persistent_equals_two_kernel(hip_lib, "fitness_T6", expect_kernel=2)
     c.case_persistent_equals_two_kernel(hip_lib, "multienv_T8", expect_kernel=2)
+
+
+@pytest.mark.parametrize("name,n", [("fitness_multi_tile", 2), ("fitness_T6", 3), ("multienv_T8", 2), ("replicate_ragged", 2)])
+def test_multi_device_handle(hip_lib, monkeypatch, name, n):
+    """bb_advi_opts.n_devices: one handle, one host thread, n shards -- here all on device 0, their resident
+    launches co-resident, inboxes wired in process -- against the unsharded run."""
+    monkeypatch.setenv("BB_TUNE_NB", "16")          # >= 8 tiles per shard; all shards' small grids fit the one GPU together
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    c.case_multi_device_handle(hip_lib, name, n)
+
+
+def test_multi_device_handle_host_summed_fallback(hip_lib, monkeypatch):
+    monkeypatch.setenv("BB_TUNE_NB", "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    c.case_multi_device_handle(hip_lib, "multienv", 2, expect_resident=False, launch_mode=1)
+    c.case_multi_device_handle(hip_lib, "genotype", 3, expect_resident=False)
