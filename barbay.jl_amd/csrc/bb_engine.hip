@@ -398,6 +398,12 @@ static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = fal
 }
 #endif
 
+// the time-point count where all replicates share it (the compile-time-T instances), else 0
+static int uniform_T(const DevModel& M) {
+    for (int r = 1; r < M.R; ++r) if (M.T[r] != M.T[0]) return 0;
+    return M.T[0];
+}
+
 #ifndef BB_EMU
 typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
 static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
@@ -406,27 +412,35 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
     if (nthr > 512 && P == 1 && kind == 0) return T == 8 ? k_res<0, 1, 1024, false, 8> : k_res<0, 1, 1024, false>;
     if (nthr > 512 && P == 1 && kind == 1) return T == 6 ? k_res<1, 1, 1024, false, 6> : k_res<1, 1, 1024, false>;
     if (nthr > 256 && nthr <= 512 && P == 2 && kind == 0) return T == 8 ? k_res<0, 2, 512, false, 8> : k_res<0, 2, 512, false>;
+    if (nthr > 256 && nthr <= 512 && P == 3 && kind == 3) return T == 6 ? k_res<3, 3, 512, false, 6> : k_res<3, 3, 512, false>;
+    if (nthr > 256 && nthr <= 512 && P == 2 && kind == 3) return T == 6 ? k_res<3, 2, 512, false, 6> : k_res<3, 2, 512, false>;
     return nullptr;
 #else
     // the BASELINE shapes' time-point counts as compile-time constants (the unit threads then read whole rows at once), in the
     // geometries those workloads and their shards use; everything else reads T from the descriptor
 #define BR_T(K, PP, NT, TT) if (kind == (K) && P == (PP) && T == (TT)) return xg ? k_res<K, PP, NT, true, TT> : k_res<K, PP, NT, false, TT>;
     if (nthr > 512) { BR_T(0, 1, 1024, 8) BR_T(0, 1, 1024, 6) BR_T(1, 1, 1024, 8) BR_T(1, 1, 1024, 6) }
-    else if (nthr > 256) { BR_T(0, 1, 512, 8) BR_T(0, 2, 512, 8) BR_T(1, 1, 512, 6) BR_T(1, 2, 512, 6) }
+    else if (nthr > 256) { BR_T(0, 1, 512, 8) BR_T(0, 2, 512, 8) BR_T(1, 1, 512, 6) BR_T(1, 2, 512, 6) BR_T(3, 2, 512, 6) BR_T(3, 3, 512, 6) BR_T(4, 3, 512, 6) }
 #undef BR_T
 #define BR_CASE(K, PP, NT) case (K) * 10 + (PP): return xg ? k_res<K, PP, NT, true> : k_res<K, PP, NT, false>;
     if (nthr > 512) {          // 16 waves per CU: 128 registers per lane
-        switch (kind * 10 + P) { BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) default: return nullptr; }
+        switch (kind * 10 + P) {
+            BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) BR_CASE(3, 1, 1024) BR_CASE(4, 1, 1024)
+            default: return nullptr;
+        }
     }
     if (nthr > 256) {          // 8 waves per CU: 256 registers per lane
         switch (kind * 10 + P) {
             BR_CASE(0, 1, 512) BR_CASE(0, 2, 512) BR_CASE(0, 3, 512) BR_CASE(1, 1, 512) BR_CASE(1, 2, 512) BR_CASE(1, 3, 512)
+            BR_CASE(3, 1, 512) BR_CASE(3, 2, 512) BR_CASE(3, 3, 512) BR_CASE(4, 1, 512) BR_CASE(4, 2, 512) BR_CASE(4, 3, 512)
             default: return nullptr;
         }
     }
     switch (kind * 10 + P) {   // 4 waves per CU: 512 registers per lane
         BR_CASE(0, 1, 256) BR_CASE(0, 2, 256) BR_CASE(0, 3, 256) BR_CASE(0, 4, 256)
         BR_CASE(1, 1, 256) BR_CASE(1, 2, 256) BR_CASE(1, 3, 256) BR_CASE(1, 4, 256)
+        BR_CASE(3, 1, 256) BR_CASE(3, 2, 256) BR_CASE(3, 3, 256) BR_CASE(3, 4, 256)
+        BR_CASE(4, 1, 256) BR_CASE(4, 2, 256) BR_CASE(4, 3, 256) BR_CASE(4, 4, 256)
         default: return nullptr;
     }
 #undef BR_CASE
@@ -485,7 +499,7 @@ static bool try_resident(bb_handle* h) {
     const BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on);
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
-    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, h->M.T[0]);
+    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M));
     if (!k) return false;
     const int lds = Y.total * 8;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
@@ -637,9 +651,9 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             if (xg) br_xchg_consume<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             else br_xchg_consume<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
-            if (h->M.T[0] == 8) br_update<KIND, PP, 8>(cx, h->M, h->S, A, Y, sb, step, buf);
-            else if (h->M.T[0] == 6) br_update<KIND, PP, 6>(cx, h->M, h->S, A, Y, sb, step, buf);
-            else br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf);
+            if (uniform_T(h->M) == 8) br_update<KIND, PP, 8>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
+            else if (uniform_T(h->M) == 6) br_update<KIND, PP, 6>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
+            else br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
         } else {
             br_epilogue<PP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
@@ -657,8 +671,12 @@ static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long lo
             default: emu_res_phase<KIND, 4>(E, phase, it, nsteps);
             }
         };
-        if (E.h->M.kind == 0) byP(std::integral_constant<int, 0>{});
-        else byP(std::integral_constant<int, 1>{});
+        switch (E.h->M.kind) {
+        case 0: byP(std::integral_constant<int, 0>{}); break;
+        case 1: byP(std::integral_constant<int, 1>{}); break;
+        case 3: byP(std::integral_constant<int, 3>{}); break;
+        default: byP(std::integral_constant<int, 4>{});
+        }
         return;
     }
     auto byP = [&](auto kindc) {
@@ -731,7 +749,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
-    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, h->M.T[0]) : nullptr;
+    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M)) : nullptr;
     if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)

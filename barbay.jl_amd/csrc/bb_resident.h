@@ -54,15 +54,15 @@ struct BRLay {
     int zr0[BB_MAX_REP]; // T_r + 1 doubles apart: with the natural stride T_r (8: 64 B) the unit threads' walks along their barcodes'
                          // rows (two barcodes per lane) land all 64 lanes in two banks -- measured: the unit waves' G pass took
                          // 14 k cycles against 5 k for the loglambda waves
-    int st[4], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w, 2 = logsigma
-                         //                                  hierarchical        0 = theta_tilde, 1 = e^logtau, 2 = w, 3 = theta
+    int st[6], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w = e^{-2 logsigma}, 2 = logsigma
+                         //   hierarchical  0 = theta_tilde, 1 = e^logtau, 2 = w, 3 = theta, 4 = logtau, 5 = logsigma
     int eps;             // [P * NT] bb_d2: the next step's normals
     int hbuf;            // [P][2][NT] bb_d2: this step's TruncatedADAGrad window slot, fetched by LDS-DMA while the exchange is in flight
                          // (no registers held across the exchange); shares the moment contributions' region (dead by then) unless the
                          // cross-GPU inbox staging needs it at the same time
-    int racc, rstride, rwidth;   // [12][rstride] the moment contributions of threads 0 .. rwidth-1 (the loglambda lanes), transposed;
-                         // rstride = rwidth + 4: the 12 columns start in different banks
-    int rowmap;          // [K] ints: time-pair class k | value index v << 8 | used << 16
+    int racc;            // the moment contributions, transposed: per replicate r [12][rw[r] + 4] at racc_r[r], one column entry per lane
+    int racc_r[BB_MAX_REP], rw[BB_MAX_REP];   // of the replicate's loglambda segment (rw = its lanes, whole waves; + 4: the 12 columns start in different banks)
+    int rowmap;          // [K] ints: time-pair class k | value index v << 8 | replicate << 16 | used << 24
     int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
     int envt;            // [Ttot] ints: environment of every time point (multienv)
     int seg;             // BRSeg table
@@ -85,7 +85,7 @@ static inline long long br_tile_span(const DevModel& M, long long NB, bool globa
 }
 
 static inline bool br_eligible(const DevModel& M) {
-    if (M.kind != 0 && M.kind != 1) return false;
+    if (M.kind == 2) return false;                 // (genotype model: its theta block needs a second exchange)
     if (M.quirk || M.Ttot > 64) return false;
     for (int r = 0; r < M.R; ++r) if ((M.T[r] & 1) || M.T[r] > BR_MAXT) return false;
     if (M.blk_lo[BK_L] & 1) return false;
@@ -111,15 +111,9 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     Y.NBT = (Y.NBT + 1) & ~1;
     Y.zl = o;      o += 2 * Y.NBT;
     Y.SU = NB * X;
-    Y.nst = M.kind <= 1 ? 3 : 4;
-    for (int i = 0; i < 4; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
+    Y.nst = M.kind <= 1 ? 3 : 6;
+    for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
     o = (o + 1) & ~1;
-    Y.eps = o;     o += 2 * P * NT;
-    {   // lanes of the loglambda segment, rounded up to whole waves (unit lanes beyond them contribute nothing)
-        long long w = ((long long)NB * Y.lpb[0] + 63) & ~63ll;
-        Y.rwidth = (int)(w < NT ? w : NT);
-        Y.rstride = Y.rwidth + 4;
-    }
     Y.rowmap = o;  o += (M.K + 1) / 2 + 1;
     L.wk = o;      o += KK;
     L.zgl = o;     o += 2 * M.nt1;
@@ -139,11 +133,20 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     Y.seg = o;     o += BR_SEG_DOUBLES * (BB_MAX_SEG + 1);
     L.seg = Y.seg;
     o = (o + 1) & ~1;
-    // one transient region, two users that never overlap in time: the transposed moment contributions (M pass -> row sums) and the
-    // staging of the cross-GPU inbox rows (bbp_consume<true>)
-    Y.racc = Y.hbuf = o;
-    { const int need = BR_NCV * Y.rstride > 4 * P * NT ? BR_NCV * Y.rstride : 4 * P * NT; o += need; }
-    L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;
+    // One transient region, users that never overlap in time: the transposed moment contributions (M pass -> row sums), then --
+    // from the publish of the tile's row to the next step's S / G passes -- the drawn-ahead normals and the prefetched window slot.
+    o = (o + 1) & ~1;
+    Y.racc = o;
+    int racc_total = 0;
+    for (int r = 0; r < BB_MAX_REP; ++r) {
+        Y.racc_r[r] = Y.racc + racc_total;
+        Y.rw[r] = r < M.R ? (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll) : 0;
+        if (r < M.R) racc_total += BR_NCV * (Y.rw[r] + 4);
+    }
+    Y.hbuf = Y.racc;
+    Y.eps = Y.hbuf + 4 * P * NT;
+    { const int need = racc_total > 6 * P * NT ? racc_total : 6 * P * NT; o += need; }
+    L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;     // staging of the cross-GPU inbox rows (bbp_consume<true>): in use while the slot / normals wait
     L.red = o;     o += KK + 16;
     (void)lmax;
     L.total = Y.total = (o + 1) & ~1;
@@ -162,6 +165,9 @@ struct BRSt {
     int uo[P][3];                       // loglambda, mutant: stage-table index of the unit the backward / inner / forward difference uses;
                                         // unit pairs: [0], [1] = zl-buffer offset of the barcode row of latent 0 / 1, [2] = env of latent 0 | env of latent 1 << 8
     int pt[P];                          // loglambda: tcum[r] + t0; unit pairs: tcum[r]
+    int rb[P];                          // loglambda: where the pair's 12 moment contributions go (racc_r[r] + lane position in its segment);
+                                        // hierarchical unit pairs and loglambda pairs: see thoff
+    int thoff[P];                       // hierarchical models: stage index of a unit minus thoff = index of its theta (r NB E_)
     unsigned cnt[P][2];                 // loglambda: the two counts
 };
 
@@ -196,7 +202,7 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
         BRSeg s;
         s.lo = lo; s.hi = lo + cnt; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.lpb = lpb; s.T = T;
         s.pm = M.pri[blk].mean; s.iv = M.pri[blk].inv_var; s.mean_e = M.pri[blk].mean_e; s.iv_e = M.pri[blk].inv_var_e; s.blo = M.blk_lo[blk];
-        if (kind == SK_L) { cur = (cur + 63) & ~63; s.span = (int)(cnt / T) * lpb; }
+        if (kind == SK_L) { cur = (cur + 63) & ~63; s.span = (int)(cnt / T) * lpb; }   // (T == 0 only for non-loglambda segments)
         else s.span = bb_seg_pairs(lo, lo + cnt);
         s.tbeg = cur;
         cur += s.span;
@@ -207,8 +213,18 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
     if (t.nmt > 0) {
         if (KIND == 0 || KIND == 1) {
             const int E = KIND == 1 ? M.E : 1;
-            add(BK_S, SK_S, M.blk_lo[BK_S] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, 0);
-            add(BK_LS, SK_LS_E, M.blk_lo[BK_LS] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, 0);
+            add(BK_S, SK_S, M.blk_lo[BK_S] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, M.T[0]);
+            add(BK_LS, SK_LS_E, M.blk_lo[BK_LS] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, M.T[0]);
+        } else {   // replicate (E_ = 1) and multienv_replicate: theta[e, m]; per replicate tt / lt / ls [e, m, r], env fastest;
+                   // ldsoff = stage index of the segment's first latent (unit (ml, r, e): (r NB + ml) E_ + e; theta: ml E_ + e)
+            const int E_ = KIND == 4 ? M.E : 1;
+            add(BK_S, SK_TH_R, M.blk_lo[BK_S] + t.m0 * E_, (long long)t.nmt * E_, 0, 0, 0, 0);
+            for (int r = 0; r < M.R; ++r) {
+                const long long o = ((long long)r * M.nb + t.m0) * E_;
+                add(BK_TT, SK_TT_R, M.blk_lo[BK_TT] + o, (long long)t.nmt * E_, r * t.NB * E_, r, 0, M.T[r]);
+                add(BK_LT, SK_LT_R, M.blk_lo[BK_LT] + o, (long long)t.nmt * E_, r * t.NB * E_, r, 0, M.T[r]);
+                add(BK_LS, SK_LS_R, M.blk_lo[BK_LS] + o, (long long)t.nmt * E_, r * t.NB * E_, r, 0, M.T[r]);
+            }
         }
     }
     if (globals) {
@@ -230,12 +246,12 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
     const int KK = M.K + 2 * M.nt1;
     BB_PASS(cx, tid) {
         // li[1] = exchange ok word; it starts at 0 ("leave") while an earlier launch's timeout is unacknowledged by the host
-        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; }
+        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = t.nbt; }
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
         for (int i = tid; i < 2 * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
         for (int i = tid; i < 2 * Y.nst * Y.SU; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
         if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
-        if (tid < M.Ttot) ((int*)(lds + Y.envt))[tid] = KIND == 1 ? M.env_idx[tid] : 0;
+        if (tid < M.Ttot) ((int*)(lds + Y.envt))[tid] = (KIND == 1 || KIND == 4) ? M.env_idx[tid] : 0;
     }
     BB_SYNC(cx);
     BB_PASS(cx, tid) {
@@ -244,29 +260,32 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
         const int nseg = li[0];
         for (int j = tid; j < M.K; j += cx.nthr) {
             int code = 0;
-            const int r = 0, T = M.T[0], q0 = j - M.kq[r];      // (one loglambda segment: fitness / multienv have no replicates)
-            if (q0 >= 0 && q0 < 6 * T - 5) {
+            for (int r = 0; r < M.R; ++r) {
+                const int T = M.T[r], q0 = j - M.kq[r];
+                if (q0 < 0 || q0 >= 6 * T - 5) continue;
                 int tt, q;
                 if (q0 < T) { tt = q0; q = 0; } else { tt = (q0 - T) / 5; q = 1 + (q0 - T) - 5 * tt; }
-                code = (tt >> 1) | (((tt & 1) * 6 + q) << 8) | (1 << 16);
+                code = (tt >> 1) | (((tt & 1) * 6 + q) << 8) | (r << 16) | (1 << 24);
             }
             rm[j] = code;
         }
         BRSt<P>& st = BB_PSTATE(stv, tid);
-        const int E = KIND == 1 ? M.E : 1;
+        const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int p = tid + k * cx.nthr;
             int si = -1;
             for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
-            int meta = 0;
+            int meta = 15;                          // (kind 15: no segment -- SK_L is 0)
             long long i0 = 0;
             st.zoff[k] = 0; st.uo[k][0] = st.uo[k][1] = st.uo[k][2] = 0; st.pt[k] = 0; st.cnt[k][0] = st.cnt[k][1] = 0u;
+            st.rb[k] = 0; st.thoff[k] = 0;
             if (si >= 0) {
                 const BRSeg s = sg[si];
                 meta = s.kind | (si << 12);
                 if (s.kind == SK_L) {
                     const int q = p - s.tbeg, bl = q / s.lpb, kk = q - bl * s.lpb;
+                    st.rb[k] = Y.racc_r[s.r] + q;           // (every lane of the segment's waves has a column entry; idle lanes write zeros)
                     if (2 * kk < s.T) {
                         const int t0 = 2 * kk;
                         i0 = s.lo + (long long)bl * s.T + t0;
@@ -276,10 +295,14 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                         if (bl >= t.nshift) {
                             meta |= BRM_MUT;
                             const int ml = bl - t.nshift;
-                            for (int d = 0; d < 3; ++d) {     // differences t0-1, t0, t0+1 use the unit of time step (t0 - 1 + d)
+                            // stage index of the unit (ml [, r] [, e]) -- fitness: ml; multienv: ml E + e; replicate: r NB + ml;
+                            // multienv_replicate: (r NB + ml) E + e -- for the differences t0-1, t0, t0+1 (environment of t + 1)
+                            const int base = KIND >= 3 ? (s.r * t.NB + ml) * E : ml * E;
+                            st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : 0;
+                            for (int d = 0; d < 3; ++d) {
                                 const int tt = t0 - 1 + d;
-                                const int e = (KIND == 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
-                                st.uo[k][d] = ml * E + e;
+                                const int e = (E > 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
+                                st.uo[k][d] = base + e;
                             }
                         }
                         const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
@@ -291,18 +314,20 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                     i0 = 2 * ((s.lo >> 1) + q);
                     const bool a0 = i0 >= s.lo, a1 = i0 + 1 < s.hi;
                     meta |= (a0 ? BRM_A0 : 0) | (a1 ? BRM_A1 : 0) | BRM_VALID;
-                    st.zoff[k] = (int)(i0 - s.lo);        // (may be -1 for a pair that starts one latent before the segment)
-                    if (s.kind == SK_S || s.kind == SK_LS_E) {
-                        // unit (ml, e) of latent x: index j = zoff + x = ml * E + e; its barcode's z row inside a zl buffer
+                    st.zoff[k] = s.ldsoff + (int)(i0 - s.lo);      // stage index of latent 0 (may sit one before the segment: never stored)
+                    st.thoff[k] = s.ldsoff;                          // (hierarchical: r NB E_; the theta of unit j is j - thoff)
+                    if (s.kind < SK_GS) {
+                        // unit (ml, e) of latent x: index j = (i0 - lo) + x = ml * E + e inside the segment; its barcode's local index
                         int env = 0;
                         for (int x = 0; x < 2; ++x) {
-                            int j = st.zoff[k] + x;
+                            int j = (int)(i0 - s.lo) + x;
                             if (j < 0) j = 0;
                             const int ml = j / E, e = j - ml * E;
-                            st.uo[k][x] = Y.zr0[0] + (t.nshift + ml) * (M.T[0] + 1);
+                            st.uo[k][x] = t.nshift + ml;
                             env |= e << (8 * x);
                         }
                         st.uo[k][2] = env;
+                        st.pt[k] = s.r;
                     }
                 }
             }
@@ -350,6 +375,19 @@ BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* 
     }
 }
 
+// stage tables of the unit kinds (BRLay.st): raw sample, transformed form (-1: none)
+BB_DEV int br_stage_raw(int kind) {
+    return kind == SK_S ? 0 : (kind == SK_LS_E ? 2 : (kind == SK_TH_R ? 3 : (kind == SK_TT_R ? 0 : (kind == SK_LT_R ? 4 : 5))));
+}
+BB_DEV int br_stage_trn(int kind) { return kind == SK_LS_E ? 1 : (kind == SK_LT_R ? 1 : (kind == SK_LS_R ? 2 : -1)); }
+// effective fitness and precision of the unit with stage index o (theta index o - thoff), from the stage buffer `sb` of this step
+template <int KIND>
+BB_DEV void br_unit_sw(const double* lds, const BRLay& Y, int buf, int o, int thoff, double* s, double* w) {
+    const double* b = lds + buf * Y.SU;
+    if (KIND <= 1) { *s = b[Y.st[0] + o]; *w = b[Y.st[1] + o]; }
+    else { *s = fma(b[Y.st[1] + o], b[Y.st[0] + o], b[Y.st[3] + o - thoff]); *w = b[Y.st[2] + o]; }
+}
+
 // ---- S: draw, stage ---------------------------------------------------------------------------------------------------
 // The long fp64 chains (softplus / sigmoid, exp) run for ALL pair slots without a branch, so that the compiler may interleave
 // the slots' chains; only the stores depend on what the pair is.
@@ -372,7 +410,8 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             st.h[k] = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
             BR_SCHED_FENCE();
             // loglambda: lambda = e^z; logsigma_bc: precision w = e^{-2 z}; (others: unused)
-            const double f = (st.meta[k] & 15) == SK_LS_E ? -2.0 : 1.0;
+            const int kd = st.meta[k] & 15;
+            const double f = (kd == SK_LS_E || kd == SK_LS_R) ? -2.0 : 1.0;      // logtau: e^{logtau}
             st.lam[k] = bb_d2{bb_exp(f * st.z[k].x), bb_exp(f * st.z[k].y)};
             BR_SCHED_FENCE();
         }
@@ -385,12 +424,15 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 double* zw = lds + Y.zl + buf * Y.NBT + st.zoff[k];                // (rows are T + 1 apart: 8-byte aligned only)
                 zw[0] = st.z[k].x;
                 zw[1] = st.z[k].y;
-            } else if (kind == SK_S || kind == SK_LS_E) {
-                double* dst = lds + Y.st[kind == SK_S ? 0 : 2] + buf * Y.SU + st.zoff[k];
+            } else if (kind < SK_GS) {
+                // unit latents: the raw sample (the G pass needs it for the prior term) and, where the (b, t) owners need another
+                // form, that form: logsigma -> w = e^{-2 logsigma}, logtau -> e^{logtau}
+                const int raw = br_stage_raw(kind), trn = br_stage_trn(kind);
+                double* dst = lds + Y.st[raw] + buf * Y.SU + st.zoff[k];
                 if (meta & BRM_A0) dst[0] = st.z[k].x;
                 if (meta & BRM_A1) dst[1] = st.z[k].y;
-                if (kind == SK_LS_E) {
-                    double* dw = lds + Y.st[1] + buf * Y.SU + st.zoff[k];
+                if (trn >= 0) {
+                    double* dw = lds + Y.st[trn] + buf * Y.SU + st.zoff[k];
                     if (meta & BRM_A0) dw[0] = st.lam[k].x;
                     if (meta & BRM_A1) dw[1] = st.lam[k].y;
                 }
@@ -434,13 +476,14 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
     double* lds = cx.lds;
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
-        double cv[BR_NCV];
-#pragma unroll
-        for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int meta = st.meta[k];
-            if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
+            if ((meta & 15) != SK_L) continue;
+            double cv[BR_NCV];
+#pragma unroll
+            for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
+            if (meta & BRM_VALID) {
             const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
             const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
             const double z0 = st.z[k].x, z1 = st.z[k].y;
@@ -449,44 +492,41 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
             cv[0] += st.lam[k].x;
             cv[6] += st.lam[k].y;
             if (mut) {
-                const double* ts = lds + Y.st[0] + buf * Y.SU;
-                const double* tw = lds + Y.st[1] + buf * Y.SU;
-                double wm, wn;
-                if (KIND == 1) {
-                    dm -= ts[st.uo[k][1]]; dn -= ts[st.uo[k][2]];
-                    wm = tw[st.uo[k][1]]; wn = tw[st.uo[k][2]];
-                } else {
-                    const double s = ts[st.uo[k][1]];
-                    wm = wn = tw[st.uo[k][1]];
-                    dm -= s; dn -= s;
-                }
+                double sm, sn, wm, wn;
+                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], st.thoff[k], &sm, &wm);
+                if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], st.thoff[k], &sn, &wn);
+                else { sn = sm; wn = wm; }
+                dm -= sm; dn -= sn;
                 cv[1] += wm; cv[2] += wm * dm; cv[3] += wm * dm * dm;
                 if (hn) { cv[7] += wn; cv[8] += wn * dn; cv[9] += wn * dn * dn; }
             } else {
                 cv[4] += dm; cv[5] += dm * dm;
                 if (hn) { cv[10] += dn; cv[11] += dn * dn; }
             }
-        }
-        if (tid < Y.rwidth) {
+            }
+            {   // (idle lanes of the segment write zeros: every column entry of its nbt * LPB lanes is fresh each step)
+                const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
+                const int stride = Y.rw[sgk->r] + 4;
 #pragma unroll
-            for (int q = 0; q < BR_NCV; ++q) lds[Y.racc + q * Y.rstride + tid] = cv[q];
+                for (int q = 0; q < BR_NCV; ++q) lds[st.rb[k] + q * stride] = cv[q];
+            }
         }
     }
     BB_SYNC(cx);                     // barrier 2: the contributions are in LDS
     BB_STAMP(cx, S, 23);
     const int KK = M.K + 2 * M.nt1;
     const int* rm = (const int*)(lds + Y.rowmap);
-    const int lpb = Y.lpb[0], nk = Y.rwidth / lpb;
+    const int nbt = ((const int*)(lds + Y.L.misc))[2];          // barcodes of this tile: column entries per time-pair class
     BB_PASS(cx, tid) {
         const int c = tid & 15;
         for (int j = tid >> 4; j < M.K; j += cx.nthr >> 4) {
-            const int code = rm[j], kc = code & 255, v = (code >> 8) & 255;
-            const double* col = lds + Y.racc + v * Y.rstride + kc;
+            const int code = rm[j], kc = code & 255, v = (code >> 8) & 255, r = (code >> 16) & 255, lpb = Y.lpb[r];
+            const double* col = lds + Y.racc_r[r] + v * (Y.rw[r] + 4) + kc;
             double s = 0.0;
 #ifdef BB_EMU
-            if (c == 0 && (code >> 16)) for (int e = 0; e < nk; ++e) s += col[e * lpb];
+            if (c == 0 && (code >> 24)) for (int e = 0; e < nbt; ++e) s += col[e * lpb];
 #else
-            if (code >> 16) for (int e = c; e < nk; e += 16) s += col[e * lpb];
+            if (code >> 24) for (int e = c; e < nbt; e += 16) s += col[e * lpb];
             s = br_row16_sum(s);
 #endif
             if (c == 0) bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
@@ -570,7 +610,7 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
 // for the loglambda waves and the whole tile waited for them).
 template <int KIND, int P, int TT = 0>
 BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
-                      unsigned long long step, int buf) {
+                      unsigned long long step, int buf, int NBs) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBSlot wslot = bb_slot_of(A, step);
@@ -584,9 +624,6 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
         }
         const double* zbuf = lds + Y.zl + buf * Y.NBT;
-        const double* ts = lds + Y.st[0] + buf * Y.SU;       // s
-        const double* tw = lds + Y.st[1] + buf * Y.SU;       // w = e^{-2 logsigma}
-        const double* tl = lds + Y.st[2] + buf * Y.SU;       // logsigma
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int meta = st.meta[k];
@@ -611,14 +648,13 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
                 double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
                 if (mut) {
-                    if (KIND == 1) {
-                        ap -= ts[st.uo[k][0]]; am -= ts[st.uo[k][1]]; an -= ts[st.uo[k][2]];
-                        wp = tw[st.uo[k][0]]; wm = tw[st.uo[k][1]]; wn = tw[st.uo[k][2]];
-                    } else {
-                        const double sb = ts[st.uo[k][1]];
-                        wp = wm = wn = tw[st.uo[k][1]];
-                        ap -= sb; am -= sb; an -= sb;
-                    }
+                    double sp, sm, sn;
+                    br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], st.thoff[k], &sm, &wm);
+                    if (KIND == 1 || KIND == 4) {
+                        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], st.thoff[k], &sp, &wp);
+                        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], st.thoff[k], &sn, &wn);
+                    } else { sp = sn = sm; wp = wn = wm; }
+                    ap -= sp; am -= sm; an -= sn;
                 } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
                 const double rp = hp ? wp * (ap - lds[L.cc + pt - 1]) : 0.0;
                 const double rm = wm * (am - lds[L.cc + pt]);
@@ -626,39 +662,57 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 const double l0 = st.lam[k].x, l1 = st.lam[k].y;
                 g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm - rp;
                 g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn - rm;
-            } else if (kind == SK_S || kind == SK_LS_E) {
-                // per-unit sums over the time steps that use the unit:  As = w sum r,  Qs = w sum r^2 - n,  r = dl - s - c_t
-                const int T = TT ? TT : M.T[0], T1 = T - 1;
+            } else if (kind < SK_GS) {
+                // Unit latents.  Per unit u = (mutant [, replicate] [, environment]) the sums over the time steps that use it,
+                //   As = w sum r,  Qs = w sum r^2 - n,  r = dl - s_eff - c_t,
+                // give  d/ds_bc = As, d/dlogsigma = Qs;  hierarchical: s_eff = theta + e^{logtau} theta_tilde, so
+                //   d/dtheta_tilde = As e^{logtau},  d/dlogtau = As e^{logtau} theta_tilde,  d/dtheta = sum over replicates of As.
                 const int* envt = (const int*)(lds + Y.envt);
+                const double* stg = lds + buf * Y.SU;
+                const int E = (KIND == 1 || KIND == 4) ? M.E : 1;
                 double gx[2] = {0.0, 0.0}, zx[2] = {0.0, 0.0};
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                     if (!(x ? a1 : a0)) continue;
-                    const int j = st.zoff[k] + x;
-                    const int e = (st.uo[k][2] >> (8 * x)) & 255;
-                    const double* zr = zbuf + st.uo[k][x];
-                    const double sv = ts[j], wv = tw[j];
-                    zx[x] = kind == SK_S ? sv : tl[j];
-                    double As = 0.0, Qs = 0.0;
-                    int nn = 0;
-                    if (TT) {
-                        double zrow[TT ? TT : 1];
+                    const int j = st.zoff[k] + x;                      // stage index of the latent
+                    const int e = (st.uo[k][2] >> (8 * x)) & 255, bl = st.uo[k][x];
+                    zx[x] = stg[Y.st[br_stage_raw(kind)] + j];
+                    // replicates whose rows the latent's gradient sums over: its own; theta: all of them
+                    const int r0 = kind == SK_TH_R ? 0 : st.pt[k], r1 = kind == SK_TH_R ? M.R : r0 + 1;
+                    double acc = 0.0;
+                    for (int r = r0; r < r1; ++r) {
+                        // stage index of the unit (bl's mutant, replicate r, environment e) and its s_eff, w
+                        const int o = kind == SK_TH_R ? (r * NBs + (j / E)) * E + e : j;
+                        const int th = kind == SK_TH_R ? r * NBs * E : st.thoff[k];
+                        double sv, wv;
+                        br_unit_sw<KIND>(lds, Y, buf, o, th, &sv, &wv);
+                        const int T = TT ? TT : M.T[r], tc = M.tcum[r];
+                        const double* zr = zbuf + Y.zr0[r] + bl * (T + 1);
+                        double As = 0.0, Qs = 0.0;
+                        int nn = 0;
+                        if (TT) {
+                            double zrow[TT ? TT : 1];
 #pragma unroll
-                        for (int tt = 0; tt < TT; ++tt) zrow[tt] = zr[tt];          // the whole row in flight at once
+                            for (int tt = 0; tt < TT; ++tt) zrow[tt] = zr[tt];          // the whole row in flight at once
 #pragma unroll
-                        for (int tt = 0; tt < TT - 1; ++tt) {
-                            const bool use = KIND != 1 || envt[tt + 1] == e;
-                            const double rr = use ? (zrow[tt + 1] - zrow[tt]) - sv - lds[L.cc + tt] : 0.0;
-                            As += rr; Qs += rr * rr; nn += use ? 1 : 0;
+                            for (int tt = 0; tt < TT - 1; ++tt) {
+                                const bool use = E == 1 || envt[tc + tt + 1] == e;
+                                const double rr = use ? (zrow[tt + 1] - zrow[tt]) - sv - lds[L.cc + tc + tt] : 0.0;
+                                As += rr; Qs += rr * rr; nn += use ? 1 : 0;
+                            }
+                        } else {
+                            for (int tt = 0; tt < T - 1; ++tt) {
+                                if (E > 1 && envt[tc + tt + 1] != e) continue;
+                                const double rr = (zr[tt + 1] - zr[tt]) - sv - lds[L.cc + tc + tt];
+                                As += rr; Qs += rr * rr; ++nn;
+                            }
                         }
-                    } else {
-                        for (int tt = 0; tt < T1; ++tt) {
-                            if (KIND == 1 && envt[tt + 1] != e) continue;
-                            const double rr = (zr[tt + 1] - zr[tt]) - sv - lds[L.cc + tt];
-                            As += rr; Qs += rr * rr; ++nn;
-                        }
+                        if (kind == SK_S || kind == SK_TH_R) acc += wv * As;
+                        else if (kind == SK_LS_E || kind == SK_LS_R) acc = wv * Qs - (double)nn;
+                        else if (kind == SK_TT_R) acc = wv * As * stg[Y.st[1] + j];                          // e^{logtau}
+                        else acc = wv * As * stg[Y.st[1] + j] * stg[Y.st[0] + j];                            // logtau: e^{logtau} theta_tilde
                     }
-                    gx[x] = kind == SK_S ? wv * As : wv * Qs - (double)nn;
+                    gx[x] = acc;
                 }
                 g0 = gx[0]; g1 = gx[1]; z0 = zx[0]; z1 = zx[1];
             } else {
@@ -774,7 +828,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
             if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
-            br_update<KIND, P, TT>(cx, M, S, A, Y, &st, step, buf);
+            br_update<KIND, P, TT>(cx, M, S, A, Y, &st, step, buf, NB);
         }
     }
     br_epilogue<P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);

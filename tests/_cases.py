@@ -21,6 +21,10 @@ SYNTH = {
     "fitness_T4": ("fitness", dict(B=333, T=4, n_neutral=70)),
     "multienv_T6": ("multienv", dict(B=600, T=6, n_env=3, n_neutral=11)),
     "multienv_T8": ("multienv", dict(B=300, T=8, n_env=4, n_neutral=40)),
+    "replicate_T6": ("replicate", dict(B=301, T=6, n_rep=2, n_neutral=1)),                 # hierarchical kinds under k_res
+    "replicate_R3": ("replicate", dict(B=400, T=[6, 8, 4], n_rep=3, n_neutral=20)),        # ... ragged (all T_r even)
+    "multienv_replicate_T6": ("multienv_replicate", dict(B=150, T=6, n_rep=2, n_env=2, n_neutral=10)),
+    "multienv_replicate_R3": ("multienv_replicate", dict(B=300, T=[6, 4, 8], n_rep=3, n_env=3, n_neutral=7)),
     "multienv": ("multienv", dict(B=600, T=7, n_env=3, n_neutral=11)),
     "genotype": ("genotype", dict(B=800, T=6, n_geno=17, n_neutral=256)),
     "replicate_ragged": ("replicate", dict(B=530, T=[5, 7, 4], n_rep=3, n_neutral=20)),

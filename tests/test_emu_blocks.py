@@ -62,7 +62,8 @@ def test_persistent_equals_two_kernel(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name)
 
 
-@pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8"])
+@pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8",
+                                  "replicate_T6", "replicate_R3", "multienv_replicate_T6", "multienv_replicate_R3"])
 def test_owner_computes_launch_equals_two_kernel(emu_lib, name):
     """Even T: launch_mode 2 is k_res (bb_resident.h); same arithmetic as the two-kernel step and the oracle."""
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
@@ -75,6 +76,14 @@ def test_owner_computes_launch_geometries(emu_lib, monkeypatch, nb, nthr):
     monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
     c.case_persistent_equals_two_kernel(emu_lib, "fitness_T6", expect_kernel=2)
     c.case_persistent_equals_two_kernel(emu_lib, "multienv_T8", expect_kernel=2)
+
+
+@pytest.mark.parametrize("nb,nthr", [(24, 128), (24, 256), (40, 512), (64, 1024)])
+def test_owner_computes_launch_geometries_hierarchical(emu_lib, monkeypatch, nb, nthr):
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    c.case_persistent_equals_two_kernel(emu_lib, "replicate_R3", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(emu_lib, "multienv_replicate_T6", expect_kernel=2)
 
 
 @pytest.mark.parametrize("lead", [50, 65, 13])
@@ -127,7 +136,8 @@ def test_logdensity_grad(emu_lib, name):
 
 
 @pytest.mark.parametrize("name,world", [("fitness_multi_tile", 2), ("fitness_multi_tile", 3), ("multienv", 2), ("replicate_ragged", 2),
-                                        ("multienv_replicate", 2), ("fitness_T6", 2), ("fitness_T6", 3), ("multienv_T8", 2)])
+                                        ("multienv_replicate", 2), ("fitness_T6", 2), ("fitness_T6", 3), ("multienv_T8", 2),
+                                        ("replicate_R3", 2), ("multienv_replicate_R3", 2)])
 def test_sharded_resident_launch(emu_lib, monkeypatch, name, world):
     monkeypatch.setenv("BB_TUNE_NB", "16")         # >= 8 tiles on every rank, one pair per thread
     monkeypatch.setenv("BB_TUNE_NTHR", "512")

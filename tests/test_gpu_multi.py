@@ -114,3 +114,26 @@ def test_bench_rehearsal_two_ranks_on_one_gpu():
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["posterior_finite"] and out["replicated_latents_identical_on_all_ranks"]
     assert "resident launch" in out["config"]["collective"]
+
+
+def test_one_handle_drives_all_devices(hip_lib, monkeypatch):
+    """bb_advi_opts.n_devices over REAL peers: one process, one handle, hipDeviceEnablePeerAccess inboxes."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import _cases as c
+    n = min(_n_gpus(), 4)
+    monkeypatch.setenv("BB_TUNE_NB", "8")
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    sp = c.synth("fitness_T6", seed=4)
+    from conftest import make_engine
+    kw = dict(seed=5, window=4, resum_every=1)
+    with make_engine(sp, hip_lib, launch_mode=1, **kw) as e1:
+        e1.run(50)
+        m1, s1 = e1.posterior()
+    with make_engine(sp, hip_lib, device_ids=list(range(n)), **kw) as e:
+        e.run(20)
+        e.run(30)
+        st = e.stats()
+        m, s = e.posterior()
+    assert st["resident_kernel"] > 0, st
+    assert np.abs(m - m1).max() < 1e-8 and np.abs(s - s1).max() < 1e-8
