@@ -376,10 +376,14 @@ BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* 
 }
 
 // stage tables of the unit kinds (BRLay.st): raw sample, transformed form (-1: none)
-BB_DEV int br_stage_raw(int kind) {
-    return kind == SK_S ? 0 : (kind == SK_LS_E ? 2 : (kind == SK_TH_R ? 3 : (kind == SK_TT_R ? 0 : (kind == SK_LT_R ? 4 : 5))));
+template <int KIND> BB_DEV int br_stage_raw(int kind) {
+    if (KIND <= 1) return kind == SK_S ? 0 : 2;
+    return kind == SK_TH_R ? 3 : (kind == SK_TT_R ? 0 : (kind == SK_LT_R ? 4 : 5));
 }
-BB_DEV int br_stage_trn(int kind) { return kind == SK_LS_E ? 1 : (kind == SK_LT_R ? 1 : (kind == SK_LS_R ? 2 : -1)); }
+template <int KIND> BB_DEV int br_stage_trn(int kind) {
+    if (KIND <= 1) return kind == SK_LS_E ? 1 : -1;
+    return kind == SK_LT_R ? 1 : (kind == SK_LS_R ? 2 : -1);
+}
 // effective fitness and precision of the unit with stage index o (theta index o - thoff), from the stage buffer `sb` of this step
 template <int KIND>
 BB_DEV void br_unit_sw(const double* lds, const BRLay& Y, int buf, int o, int thoff, double* s, double* w) {
@@ -411,7 +415,7 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             BR_SCHED_FENCE();
             // loglambda: lambda = e^z; logsigma_bc: precision w = e^{-2 z}; (others: unused)
             const int kd = st.meta[k] & 15;
-            const double f = (kd == SK_LS_E || kd == SK_LS_R) ? -2.0 : 1.0;      // logtau: e^{logtau}
+            const double f = (kd == SK_LS_E || (KIND >= 3 && kd == SK_LS_R)) ? -2.0 : 1.0;      // logtau: e^{logtau}
             st.lam[k] = bb_d2{bb_exp(f * st.z[k].x), bb_exp(f * st.z[k].y)};
             BR_SCHED_FENCE();
         }
@@ -427,7 +431,7 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             } else if (kind < SK_GS) {
                 // unit latents: the raw sample (the G pass needs it for the prior term) and, where the (b, t) owners need another
                 // form, that form: logsigma -> w = e^{-2 logsigma}, logtau -> e^{logtau}
-                const int raw = br_stage_raw(kind), trn = br_stage_trn(kind);
+                const int raw = br_stage_raw<KIND>(kind), trn = br_stage_trn<KIND>(kind);
                 double* dst = lds + Y.st[raw] + buf * Y.SU + st.zoff[k];
                 if (meta & BRM_A0) dst[0] = st.z[k].x;
                 if (meta & BRM_A1) dst[1] = st.z[k].y;
@@ -493,8 +497,8 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
             cv[6] += st.lam[k].y;
             if (mut) {
                 double sm, sn, wm, wn;
-                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], st.thoff[k], &sm, &wm);
-                if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], st.thoff[k], &sn, &wn);
+                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 3 ? st.thoff[k] : 0, &sm, &wm);
+                if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
                 else { sn = sm; wn = wm; }
                 dm -= sm; dn -= sn;
                 cv[1] += wm; cv[2] += wm * dm; cv[3] += wm * dm * dm;
@@ -605,6 +609,34 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
 }
 
 // ---- G: gradients from registers, prior, optimiser, window slot -----------------------------------------------------------
+// Likelihood gradient of a loglambda pair's two latents, everything but lambda re-read from LDS (the staged samples are still
+// there): differences, a = dl - s_eff, r = a - c_t.
+template <int KIND, int P>
+BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, int buf, double* g0, double* g1) {
+    const BBLds& L = Y.L;
+    const int meta = st.meta[k], pt = st.pt[k];
+    const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+    const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
+    const double z0 = zb[0], z1 = zb[1];
+    const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
+    double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
+    if (mut) {
+        double sp, sm, sn;
+        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 3 ? st.thoff[k] : 0, &sm, &wm);
+        if (KIND == 1 || KIND == 4) {
+            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], KIND >= 3 ? st.thoff[k] : 0, &sp, &wp);
+            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
+        } else { sp = sn = sm; wp = wn = wm; }
+        ap -= sp; am -= sm; an -= sn;
+    } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
+    const double rp = hp ? wp * (ap - lds[L.cc + pt - 1]) : 0.0;
+    const double rm = wm * (am - lds[L.cc + pt]);
+    const double rn = hn ? wn * (an - lds[L.cc + pt + 1]) : 0.0;
+    const double l0 = st.lam[k].x, l1 = st.lam[k].y;
+    *g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm - rp;
+    *g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn - rm;
+}
+
 // TT > 0: the number of time points is a compile-time constant -- the unit threads then fetch their barcodes' whole rows at once
 // (with the row walk as a runtime loop, one LDS round trip per time step, the unit waves' G pass took 13 k cycles against 4 k
 // for the loglambda waves and the whole tile waited for them).
@@ -614,7 +646,11 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBSlot wslot = bb_slot_of(A, step);
+    // (Measured and dropped: letting a barcode's loglambda lanes also form its units' sums As, Qs -- a DPP sum over the LPB lanes,
+    //  two numbers per unit through LDS, one more barrier -- so that the unit threads need not walk the barcode's row: the G pass
+    //  is bound by the SIMDs' total VALU work, not by the unit waves; C2 15.3 -> 15.5 us per step, C3 unchanged.)
     BB_STAMP_WAVE(cx, S, A, 2);
+    const double* zbuf = lds + Y.zl + buf * Y.NBT;
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
         double* hs_m = nullptr;
@@ -623,7 +659,6 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dp;
             hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
         }
-        const double* zbuf = lds + Y.zl + buf * Y.NBT;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int meta = st.meta[k];
@@ -640,28 +675,9 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             }
             double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
             if (kind == SK_L) {
-                // everything but lambda is re-read from LDS (the staged samples are still there): differences, a = dl - s_eff, r = a - c
-                const int pt = st.pt[k];
-                const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
                 const double* zb = zbuf + st.zoff[k];
                 z0 = zb[0]; z1 = zb[1];
-                const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
-                double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
-                if (mut) {
-                    double sp, sm, sn;
-                    br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], st.thoff[k], &sm, &wm);
-                    if (KIND == 1 || KIND == 4) {
-                        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], st.thoff[k], &sp, &wp);
-                        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], st.thoff[k], &sn, &wn);
-                    } else { sp = sn = sm; wp = wn = wm; }
-                    ap -= sp; am -= sm; an -= sn;
-                } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
-                const double rp = hp ? wp * (ap - lds[L.cc + pt - 1]) : 0.0;
-                const double rm = wm * (am - lds[L.cc + pt]);
-                const double rn = hn ? wn * (an - lds[L.cc + pt + 1]) : 0.0;
-                const double l0 = st.lam[k].x, l1 = st.lam[k].y;
-                g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm - rp;
-                g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn - rm;
+                br_l_grad<KIND>(lds, Y, st, k, buf, &g0, &g1);
             } else if (kind < SK_GS) {
                 // Unit latents.  Per unit u = (mutant [, replicate] [, environment]) the sums over the time steps that use it,
                 //   As = w sum r,  Qs = w sum r^2 - n,  r = dl - s_eff - c_t,
@@ -676,18 +692,19 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                     if (!(x ? a1 : a0)) continue;
                     const int j = st.zoff[k] + x;                      // stage index of the latent
                     const int e = (st.uo[k][2] >> (8 * x)) & 255, bl = st.uo[k][x];
-                    zx[x] = stg[Y.st[br_stage_raw(kind)] + j];
+                    zx[x] = stg[Y.st[br_stage_raw<KIND>(kind)] + j];
                     // replicates whose rows the latent's gradient sums over: its own; theta: all of them
-                    const int r0 = kind == SK_TH_R ? 0 : st.pt[k], r1 = kind == SK_TH_R ? M.R : r0 + 1;
+                    const bool is_th = KIND >= 3 && kind == SK_TH_R;
+                    const int r0 = KIND <= 1 ? 0 : (is_th ? 0 : st.pt[k]), r1 = KIND <= 1 ? 1 : (is_th ? M.R : r0 + 1);
                     double acc = 0.0;
                     for (int r = r0; r < r1; ++r) {
                         // stage index of the unit (bl's mutant, replicate r, environment e) and its s_eff, w
-                        const int o = kind == SK_TH_R ? (r * NBs + (j / E)) * E + e : j;
-                        const int th = kind == SK_TH_R ? r * NBs * E : st.thoff[k];
+                        const int o = is_th ? (r * NBs + (j / E)) * E + e : j;
+                        const int th = KIND <= 1 ? 0 : (is_th ? r * NBs * E : st.thoff[k]);
                         double sv, wv;
                         br_unit_sw<KIND>(lds, Y, buf, o, th, &sv, &wv);
-                        const int T = TT ? TT : M.T[r], tc = M.tcum[r];
-                        const double* zr = zbuf + Y.zr0[r] + bl * (T + 1);
+                        const int T = TT ? TT : M.T[r], tc = KIND <= 1 ? 0 : M.tcum[r];
+                        const double* zr = zbuf + (KIND <= 1 ? Y.zr0[0] : Y.zr0[r]) + bl * (T + 1);
                         double As = 0.0, Qs = 0.0;
                         int nn = 0;
                         if (TT) {
@@ -707,8 +724,9 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                                 As += rr; Qs += rr * rr; ++nn;
                             }
                         }
-                        if (kind == SK_S || kind == SK_TH_R) acc += wv * As;
-                        else if (kind == SK_LS_E || kind == SK_LS_R) acc = wv * Qs - (double)nn;
+                        if (KIND <= 1) acc = kind == SK_S ? wv * As : wv * Qs - (double)nn;
+                        else if (is_th) acc += wv * As;
+                        else if (kind == SK_LS_R) acc = wv * Qs - (double)nn;
                         else if (kind == SK_TT_R) acc = wv * As * stg[Y.st[1] + j];                          // e^{logtau}
                         else acc = wv * As * stg[Y.st[1] + j] * stg[Y.st[0] + j];                            // logtau: e^{logtau} theta_tilde
                     }
