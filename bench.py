@@ -199,7 +199,10 @@ def main():
         steps_per_launch = args.steps / launches
         launch_s = st["last_run_ms"] * 1e-3 / launches
         ach = st["bytes_per_step"] * steps_per_launch / launch_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_persist", "kernel_instance": f"k_persist<{bb._capi.BB_MODEL[wl.kind]}, {int(st['persistent_pairs'])}, {1024 if int(st['block_threads']) > 512 else 512}",
+        kname = "k_res" if int(st.get("resident_kernel", 1)) == 2 else "k_persist"
+        nt = int(st["block_threads"])
+        nt_inst = 1024 if nt > 512 else (512 if (nt > 256 or kname == "k_persist") else 256)
+        roofline = {"bound": "hbm", "kernel": kname, "kernel_instance": f"{kname}<{bb._capi.BB_MODEL[wl.kind]}, {int(st['persistent_pairs'])}, {nt_inst}",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(st["bytes_per_step"] * steps_per_launch),

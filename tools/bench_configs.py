@@ -19,11 +19,11 @@ CFG = {
     "C5 genotype_fitness_normal 200000x8 G=5000": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45),
     "(no BASELINE config) multienv_replicate_fitness_normal 12000x(6,5,6) E=3": lambda: synth.multienv_replicate_fitness_normal(),
 }
-steps = int(os.environ.get("STEPS", 2000))
+steps = int(os.environ.get("STEPS", 4000))
 for name, mk in CFG.items():
     wl = mk()
     e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=1)
-    e.run(200)
+    e.run(1200)          # past the ten early windows of the default re-add schedule (one exact re-add per window there)
     t0 = time.perf_counter()
     e.run(steps)
     dt = time.perf_counter() - t0
@@ -31,6 +31,6 @@ for name, mk in CFG.items():
     print(json.dumps({"config": name, "steps_per_s": round(steps / dt, 1), "us_per_step": round(dt / steps * 1e6, 2),
                       "n_latents": st["n_latents"], "bytes_per_step": st["bytes_per_step"],
                       "frac_hbm_peak": round(st["bytes_per_step"] * steps / dt / 8e12, 4),
-                      "resident_launch_pairs": st["persistent_pairs"], "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
+                      "resident_launch_pairs": st["persistent_pairs"], "resident_kernel": {0: "none (two kernels per step)", 1: "k_persist", 2: "k_res"}[st["resident_kernel"]], "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
           flush=True)
     e.close()

@@ -22,7 +22,7 @@ tot = collections.OrderedDict()
 for f in sorted(glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        if "k_persist" in r["Kernel_Name"]:
+        if "k_res" in r["Kernel_Name"] or "k_persist" in r["Kernel_Name"]:
             per[r["Counter_Name"]][r["Dispatch_Id"]] = per[r["Counter_Name"]].get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     for c, d in per.items():
         tot[c] = max(d.values())          # the timed 2000-step launch
