@@ -1049,6 +1049,21 @@ BB_DEV void bb_block_geno(BBCtx& cx, const DevModel& M, const DevState& S, const
     }
 }
 
+// theta rows of the genotype model (mu, omega, the two accumulators, 2 W window rows) <-> a packed buffer [rows][G]; packing
+// writes zeros for the genotypes outside [g_lo, g_hi), so that the sum over all shards' buffers is the gather from the owners.
+BB_DEV void bb_block_theta_pack(BBCtx& cx, const DevModel& M, const DevState& S, double* buf, int g_lo, int g_hi, int W, int unpack, int nblocks) {
+    const long long total = (long long)(4 + 2 * W) * M.G;
+    BB_PASS(cx, tid) {
+        for (long long i = (long long)cx.block * cx.nthr + tid; i < total; i += (long long)nblocks * cx.nthr) {
+            const int a = (int)(i / M.G), g = (int)(i - (long long)a * M.G);
+            double* p = a == 0 ? S.mu : (a == 1 ? S.om : (a == 2 ? S.acc_mu : (a == 3 ? S.acc_om : S.hist + (long long)(a - 4) * M.Dp)));
+            p += M.blk_lo[BK_S] + g;
+            if (unpack) *p = buf[i];
+            else buf[i] = (g >= g_lo && g < g_hi) ? *p : 0.0;
+        }
+    }
+}
+
 // gsum[g] = sum over the genotype's mutants (CSR order) of ds: deterministic segmented sum.  Eight lanes share a
 // genotype (lane c adds members k = c, c + 8, ...), the eight partial sums are added in lane order.
 BB_DEV void bb_block_geno_sum(BBCtx& cx, const DevModel& M, const DevState& S, int nblocks, long long m_lo, long long m_hi) {

@@ -130,6 +130,10 @@ __global__ void __launch_bounds__(256) k_reduce(DevModel M, DevState S, int nblk
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_reduce(cx, M, S, nblk, ngeno_blocks);
 }
+__global__ void __launch_bounds__(256) k_theta_pack(DevModel M, DevState S, double* buf, int g_lo, int g_hi, int W, int unpack) {
+    BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
+    bb_block_theta_pack(cx, M, S, buf, g_lo, g_hi, W, unpack, (int)gridDim.x);
+}
 __global__ void __launch_bounds__(256) k_init(DevModel M, DevState S, unsigned long long seed) {
     BBCtx cx{(int)blockDim.x, (int)blockIdx.x, bb_smem};
     bb_block_init(cx, M, S, seed, (int)gridDim.x);
@@ -218,6 +222,11 @@ struct bb_handle {
     size_t lds_doubles_p0 = 0;         // ... of the resident launch (adds the lambda table)
     size_t lds_doubles_p = 0;          // ... plus the drawn-ahead normals and the cached counts (16 + 8 B per pair)
     long long b_lo = 0, b_hi = 0;      // barcode shard
+    int cus = 256;                     // compute units of the device (one resident workgroup each)
+    int g_lo = 0, g_hi = 0;            // genotype model: the genotypes whose theta this shard owns (all of them unless cut at genotype boundaries)
+    std::vector<int> geno_ptr_h;       // genotype model: CSR offsets over genotypes (sorted geno_idx: first mutant of every genotype)
+    long long* d_tile_b = nullptr;     // genotype model, k_res: the tile table (DevState.tile_b / tile_g)
+    int* d_tile_g = nullptr;
     long long step = 0;                // host mirror of the device step counter
     int sample = 0;                    // next MC sample inside the current step (split-phase API)
     double elbo_const = 0.0;
@@ -261,6 +270,8 @@ struct bb_handle {
     // single-process multi-device handle (bb_advi_opts.n_devices > 1): all the work is in the shards, one per device
     std::vector<bb_handle*> shards;
     bool group_resident = false;       // the shards run resident launches with in-process peer-mapped inboxes
+    double* theta_buf = nullptr;       // genotype model: staging of the theta rows gathered from their owners (theta_sync_*)
+    bool theta_stale = false;          // a resident run left the theta_g this shard does not own out of date
     bool in_group = false;             // this handle is a shard of a group: its peers' inboxes are plain pointers, not IPC mappings
     bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
     bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
@@ -351,6 +362,7 @@ static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean,
 struct bb_handle;
 static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
 static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
+static int theta_sync_local(bb_handle* const* hs, int n);
 #ifndef BB_EMU
 static int launch_check();
 #endif
@@ -414,24 +426,26 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
     if (nthr > 256 && nthr <= 512 && P == 2 && kind == 0) return T == 8 ? k_res<0, 2, 512, false, 8> : k_res<0, 2, 512, false>;
     if (nthr > 256 && nthr <= 512 && P == 3 && kind == 3) return T == 6 ? k_res<3, 3, 512, false, 6> : k_res<3, 3, 512, false>;
     if (nthr > 256 && nthr <= 512 && P == 2 && kind == 3) return T == 6 ? k_res<3, 2, 512, false, 6> : k_res<3, 2, 512, false>;
+    if (nthr > 512 && P == 1 && kind == 2) return T == 8 ? k_res<2, 1, 1024, false, 8> : k_res<2, 1, 1024, false>;
     return nullptr;
 #else
     // the BASELINE shapes' time-point counts as compile-time constants (the unit threads then read whole rows at once), in the
     // geometries those workloads and their shards use; everything else reads T from the descriptor
 #define BR_T(K, PP, NT, TT) if (kind == (K) && P == (PP) && T == (TT)) return xg ? k_res<K, PP, NT, true, TT> : k_res<K, PP, NT, false, TT>;
-    if (nthr > 512) { BR_T(0, 1, 1024, 8) BR_T(0, 1, 1024, 6) BR_T(1, 1, 1024, 8) BR_T(1, 1, 1024, 6) }
-    else if (nthr > 256) { BR_T(0, 1, 512, 8) BR_T(0, 2, 512, 8) BR_T(1, 1, 512, 6) BR_T(1, 2, 512, 6) BR_T(3, 2, 512, 6) BR_T(3, 3, 512, 6) BR_T(4, 3, 512, 6) }
+    if (nthr > 512) { BR_T(0, 1, 1024, 8) BR_T(0, 1, 1024, 6) BR_T(1, 1, 1024, 8) BR_T(1, 1, 1024, 6) BR_T(2, 1, 1024, 8) }
+    else if (nthr > 256) { BR_T(0, 1, 512, 8) BR_T(0, 2, 512, 8) BR_T(1, 1, 512, 6) BR_T(1, 2, 512, 6) BR_T(2, 2, 512, 8) BR_T(2, 3, 512, 8) BR_T(3, 2, 512, 6) BR_T(3, 3, 512, 6) BR_T(4, 3, 512, 6) }
 #undef BR_T
 #define BR_CASE(K, PP, NT) case (K) * 10 + (PP): return xg ? k_res<K, PP, NT, true> : k_res<K, PP, NT, false>;
     if (nthr > 512) {          // 16 waves per CU: 128 registers per lane
         switch (kind * 10 + P) {
-            BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) BR_CASE(3, 1, 1024) BR_CASE(4, 1, 1024)
+            BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) BR_CASE(2, 1, 1024) BR_CASE(3, 1, 1024) BR_CASE(4, 1, 1024)
             default: return nullptr;
         }
     }
     if (nthr > 256) {          // 8 waves per CU: 256 registers per lane
         switch (kind * 10 + P) {
             BR_CASE(0, 1, 512) BR_CASE(0, 2, 512) BR_CASE(0, 3, 512) BR_CASE(1, 1, 512) BR_CASE(1, 2, 512) BR_CASE(1, 3, 512)
+            BR_CASE(2, 1, 512) BR_CASE(2, 2, 512) BR_CASE(2, 3, 512)
             BR_CASE(3, 1, 512) BR_CASE(3, 2, 512) BR_CASE(3, 3, 512) BR_CASE(4, 1, 512) BR_CASE(4, 2, 512) BR_CASE(4, 3, 512)
             default: return nullptr;
         }
@@ -439,6 +453,7 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
     switch (kind * 10 + P) {   // 4 waves per CU: 512 registers per lane
         BR_CASE(0, 1, 256) BR_CASE(0, 2, 256) BR_CASE(0, 3, 256) BR_CASE(0, 4, 256)
         BR_CASE(1, 1, 256) BR_CASE(1, 2, 256) BR_CASE(1, 3, 256) BR_CASE(1, 4, 256)
+        BR_CASE(2, 1, 256) BR_CASE(2, 2, 256) BR_CASE(2, 3, 256) BR_CASE(2, 4, 256)
         BR_CASE(3, 1, 256) BR_CASE(3, 2, 256) BR_CASE(3, 3, 256) BR_CASE(3, 4, 256)
         BR_CASE(4, 1, 256) BR_CASE(4, 2, 256) BR_CASE(4, 3, 256) BR_CASE(4, 4, 256)
         default: return nullptr;
@@ -471,6 +486,34 @@ static int sync_descriptors(bb_handle* h) {
     return h2d(h->dY, &h->Yh, sizeof(BRLay), h->stream);
 }
 
+// Genotype model: the tile table of k_res (br_tile_geno) -- tiles of at most NB barcodes (the first eight: NBL, if > 0) whose cuts
+// inside the mutants fall on genotype boundaries; tg[i] = first genotype tile i owns.  False if a genotype does not fit a tile.
+static bool build_geno_tiles(const bb_handle* h, int NB, int NBL, std::vector<long long>& tb, std::vector<int>& tg) {
+    const DevModel& M = h->M;
+    const std::vector<int>& ptr = h->geno_ptr_h;
+    auto geno_of = [&](long long m) { return (int)(std::upper_bound(ptr.begin(), ptr.end(), (int)m) - ptr.begin()) - 1; };
+    auto gcut = [&](long long b) { return (b <= M.nn || b <= h->b_lo) ? h->g_lo : (b >= h->b_hi ? h->g_hi : geno_of(b - M.nn)); };
+    tb.clear();
+    tg.clear();
+    long long b = h->b_lo;
+    while (b < h->b_hi) {
+        const int cap = (NBL > 0 && tb.size() < 8) ? NBL : NB;
+        long long e = std::min<long long>(b + cap, h->b_hi);
+        if (e < h->b_hi && e > M.nn) {
+            e = M.nn + ptr[(size_t)geno_of(e - M.nn)];       // back to the first mutant of the genotype the cut fell into
+            if (e <= b) return false;
+        }
+        tb.push_back(b);
+        tg.push_back(gcut(b));
+        b = e;
+    }
+    if (tb.empty()) { tb.push_back(h->b_lo); tg.push_back(h->g_lo); }
+    tb.push_back(h->b_hi);
+    tg.push_back(h->g_hi);
+    for (size_t i = 0; i + 1 < tg.size(); ++i) if (tg[i + 1] - tg[i] > NB) return false;      // (theta stage table: NB entries)
+    return NB < 32768;
+}
+
 // the owner-computes launch (bb_resident.h) where the shape allows it; BB_NO_RES=1 keeps k_persist (A/B runs)
 static bool try_resident(bb_handle* h) {
     const char* ev = getenv("BB_NO_RES");
@@ -494,6 +537,21 @@ static bool try_resident(bb_handle* h) {
         // stay uniform where rounding pushed the map over the grid that fits, or the slightly larger tiles need another pair slot
         if (nblk > h->nblk + (nb_fixed ? 8 : 0) || p_new > p_uni) { NB = h->NB; NBL = 0; nblk = h->nblk; }
     }
+    std::vector<long long> tb;
+    std::vector<int> tg;
+    if (h->M.kind == BB_MODEL_GENOTYPE) {
+        // cuts on genotype boundaries leave tiles partly empty: grow the tile until the map fits the grid again
+        const int limit = std::max(h->nblk, std::min(h->nblk + 8, h->cus));      // (the exchange buffers hold nblk + 8 tiles)
+        bool ok = false;
+        for (int grow = 0; grow <= NB / 2 + 8 && !ok; ++grow) {
+            const int nb = NB + grow, nbl = NBL > 0 ? std::max(1, (int)((long long)NBL * nb / NB)) : 0;
+            if (build_geno_tiles(h, nb, nbl, tb, tg) && (int)tb.size() - 1 <= limit) { ok = true; NB = nb; NBL = nbl; }
+            else if (nb_fixed && NBL > 0 && build_geno_tiles(h, nb, 0, tb, tg) && (int)tb.size() - 1 <= limit) { ok = true; NB = nb; NBL = 0; }
+        }
+        if (!ok) return false;
+        nblk = (int)tb.size() - 1;
+        if (h->p2p_on && nblk < 8) return false;
+    }
     const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
     if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
     const BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on);
@@ -508,6 +566,12 @@ static bool try_resident(bb_handle* h) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, h->nthr, (size_t)lds) != hipSuccess ||
         hipGetDeviceProperties(&pr, h->o.device) != hipSuccess || (long long)per_cu * pr.multiProcessorCount < nblk) return false;
 #endif
+    if (h->M.kind == BB_MODEL_GENOTYPE) {
+        if (!h->d_tile_b && (dalloc(h, &h->d_tile_b, (size_t)h->nblk + 10) || dalloc(h, &h->d_tile_g, (size_t)h->nblk + 10))) return false;
+        if (h2d(h->d_tile_b, tb.data(), tb.size() * 8, h->stream) || h2d(h->d_tile_g, tg.data(), tg.size() * 4, h->stream)) return false;
+        h->S.tile_b = h->d_tile_b;
+        h->S.tile_g = h->d_tile_g;
+    }
     h->Yh = Y;
     h->res_P = P;
     h->res_NB = NB;
@@ -526,9 +590,10 @@ static int setup_persistent(bb_handle* h) {
     else if (h->force_reduce || (h->o.world_size != 1 && !h->p2p_on)) why = "sharded run";
     else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";   // (k_res's own tile map never has fewer tiles than this one)
     else if (h->o.elbo_every != 0) why = "ELBO recording is on";
-    else if (h->M.kind == BB_MODEL_GENOTYPE) why = "genotype model (second exchange per step)";
     h->res_P = 0;
     if (!why && want && try_resident(h)) { h->persist_P = h->res_P; return 0; }
+    if (!why && h->M.kind == BB_MODEL_GENOTYPE)
+        why = h->M.geno_sorted ? "genotype model: no tile map with whole genotypes per tile fits the device" : "genotype model: geno_idx is not in consecutive runs (a tile must hold whole genotypes)";
     int P = 0;
     if (!why) {
         P = (int)((tile_pairs_bound(h->M, h->NB) + h->nthr - 1) / h->nthr);
@@ -674,6 +739,7 @@ static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long lo
         switch (E.h->M.kind) {
         case 0: byP(std::integral_constant<int, 0>{}); break;
         case 1: byP(std::integral_constant<int, 1>{}); break;
+        case 2: byP(std::integral_constant<int, 2>{}); break;
         case 3: byP(std::integral_constant<int, 3>{}); break;
         default: byP(std::integral_constant<int, 4>{});
         }
@@ -732,7 +798,9 @@ extern "C" int bb_emu_run_group(bb_handle** hs, int32_t n, int64_t nsteps) {
     for (int i = 0; i < n; ++i)
         if (!hs[i] || hs[i]->persist_P == 0) return bb_fail(BB_ERR_INVALID, "handle %d has no resident launch", i);
     for (int i = 0; i < n; ++i) hs[i]->req_steps += nsteps;
-    return emu_run_group(hs, n, nsteps);
+    int rc = emu_run_group(hs, n, nsteps);
+    if (!rc) rc = theta_sync_local(hs, n);          // (genotype model: theta_g back from its owner, as bb_run does through RCCL)
+    return rc;
 }
 #endif
 
@@ -946,6 +1014,9 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
         BB_TRY(h2d(dm, mem.data(), (size_t)M.nb * 4, h->stream));
         M.geno_ptr = dp;
         M.geno_mem = dm;
+        M.geno_sorted = 1;
+        for (long long m = 1; m < M.nb; ++m) if (md->geno_idx[m] < md->geno_idx[m - 1]) { M.geno_sorted = 0; break; }
+        h->geno_ptr_h = ptr;
     }
 
     // ---- priors (defaults: model_fitness_normal.jl:125-129, ..._genotypes.jl:162) -------------
@@ -970,6 +1041,24 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     // ---- shard + launch geometry -------------------------------------------------------------
     h->b_lo = M.B * opts->rank / opts->world_size;
     h->b_hi = M.B * (opts->rank + 1) / opts->world_size;
+    h->g_lo = 0;
+    h->g_hi = M.G;
+    if (M.kind == BB_MODEL_GENOTYPE && M.geno_sorted && opts->world_size > 1) {
+        // Genotypes in consecutive runs: cut the shards at genotype boundaries, so that every rank holds ALL mutants of the
+        // genotypes it owns -- d/dtheta_g is then a rank-local sum.  The cut moves back to the first mutant
+        // of the genotype it fell into; genotypes without mutants go with the one before.
+        auto snap = [&](long long b, int* g) {
+            if (b <= 0) { *g = 0; return (long long)0; }
+            if (b >= M.B) { *g = M.G; return M.B; }
+            if (b <= M.nn) { *g = 0; return b; }
+            const int gg = md->geno_idx[b - M.nn];
+            *g = gg;
+            return M.nn + (long long)h->geno_ptr_h[(size_t)gg];
+        };
+        h->b_lo = snap(h->b_lo, &h->g_lo);
+        h->b_hi = snap(h->b_hi, &h->g_hi);
+        if (h->b_lo <= M.nn) h->g_lo = 0;          // (genotype ranges tile [0, G): whoever owns the first mutant also owns the empty ones before it)
+    }
     {
         // One workgroup per CU (XCD-agnostic: every tile is independent), sized so that the whole
         // shard is resident at once: NB = ceil(barcodes / CUs) barcodes per tile, up to 1024 threads
@@ -980,6 +1069,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
 #ifndef BB_EMU
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, opts->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
 #endif
+        h->cus = cus;
         const char* ev;
         int bpc = (ev = getenv("BB_TUNE_BLOCKS_PER_CU")) ? atoi(ev) : 1;
         if (bpc < 1) bpc = 1;
@@ -1246,6 +1336,51 @@ static int allreduce(bb_handle* h, double* buf, size_t n) {
 #endif
 }
 
+// Genotype model with the shards cut at genotype boundaries: a resident run updates theta_g on its owner only.  Gathering the
+// owners' copies (parameters, optimiser accumulators, window rows) = summing rows that hold zeros for what a shard does not own.
+static size_t theta_rows(const bb_handle* h) { return 4 + (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD ? 2 * (size_t)h->o.window : 0); }
+static bool theta_partial(const bb_handle* h) { return h->M.kind == BB_MODEL_GENOTYPE && (h->g_lo > 0 || h->g_hi < h->M.G); }
+static int theta_pack(bb_handle* h, int unpack) {
+    const size_t n = theta_rows(h) * (size_t)h->M.G;
+    int rc;
+    if (!h->theta_buf && (rc = dalloc(h, &h->theta_buf, n))) return rc;
+    const int W = h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD ? h->o.window : 0;
+    const int nb = (int)std::min<size_t>((n + 255) / 256, 512);
+#ifdef BB_EMU
+    emu_launch(nb, 256, 0, [&](BBCtx& cx) { bb_block_theta_pack(cx, h->M, h->S, h->theta_buf, h->g_lo, h->g_hi, W, unpack, nb); });
+#else
+    hipLaunchKernelGGL(k_theta_pack, dim3(nb), dim3(256), 0, h->stream, h->M, h->S, h->theta_buf, h->g_lo, h->g_hi, W, unpack);
+#endif
+    return LAUNCH_CHECK();
+}
+// ranks of a multi-process run: through the RCCL communicator (collective: every rank is here after the same bb_run)
+static int theta_sync_comm(bb_handle* h) {
+    int rc;
+    if ((rc = theta_pack(h, 0))) return rc;
+    if ((rc = allreduce(h, h->theta_buf, theta_rows(h) * (size_t)h->M.G))) return rc;
+    if ((rc = theta_pack(h, 1))) return rc;
+    h->theta_stale = false;
+    return dsync(h->stream);
+}
+// handles of one process (the shards of a multi-device handle; the emulation's ranks): summed on the host
+static int theta_sync_local(bb_handle* const* hs, int n) {
+    if (n < 2 || !theta_partial(hs[0])) return 0;
+    const size_t len = theta_rows(hs[0]) * (size_t)hs[0]->M.G;
+    std::vector<double> part(len), total(len, 0.0);
+    int rc;
+    for (int i = 0; i < n; ++i) {
+        BB_ENTER(hs[i]);
+        if ((rc = theta_pack(hs[i], 0)) || (rc = d2h(part.data(), hs[i]->theta_buf, len * 8, hs[i]->stream))) return rc;
+        for (size_t k = 0; k < len; ++k) total[k] += part[k];
+    }
+    for (int i = 0; i < n; ++i) {
+        BB_ENTER(hs[i]);
+        if ((rc = h2d(hs[i]->theta_buf, total.data(), len * 8, hs[i]->stream)) || (rc = theta_pack(hs[i], 1)) || (rc = dsync(hs[i]->stream))) return rc;
+        hs[i]->theta_stale = false;
+    }
+    return 0;
+}
+
 // first half of one MC sample: draw + moments (+ reduce to totals when sharded / genotype)
 static int sample_half(bb_handle* h, const RunArgs& A) {
     int rc;
@@ -1329,11 +1464,12 @@ static void owned_ranges(const bb_handle* sh, std::vector<std::pair<long long, l
     const long long b_lo = sh->b_lo, b_hi = sh->b_hi;
     const long long m_lo = std::max(b_lo, M.nn) - M.nn, m_hi = std::max(b_hi, M.nn) - M.nn;
     for (int r = 0; r < M.R; ++r) out.push_back({M.off_l[r] + b_lo * M.T[r], M.off_l[r] + b_hi * M.T[r]});
+    if (M.kind == BB_MODEL_GENOTYPE && sh->g_hi > sh->g_lo) out.push_back({M.blk_lo[BK_S] + sh->g_lo, M.blk_lo[BK_S] + sh->g_hi});   // theta of its own genotypes
     if (m_hi <= m_lo) return;
     if (M.kind == BB_MODEL_FITNESS || M.kind == BB_MODEL_MULTIENV) {
         out.push_back({M.blk_lo[BK_S] + m_lo * M.E, M.blk_lo[BK_S] + m_hi * M.E});
         out.push_back({M.blk_lo[BK_LS] + m_lo * M.E, M.blk_lo[BK_LS] + m_hi * M.E});
-    } else if (M.kind == BB_MODEL_GENOTYPE) {      // (theta is per genotype: replicated, taken from shard 0)
+    } else if (M.kind == BB_MODEL_GENOTYPE) {      // (theta: above -- sharded by genotype where the cuts allow, else all shards hold all of it)
         for (int k : {BK_TT, BK_LT, BK_LS}) out.push_back({M.blk_lo[k] + m_lo, M.blk_lo[k] + m_hi});
     } else {
         const long long E_ = M.kind == BB_MODEL_MULTIENV_REPLICATE ? M.E : 1;
@@ -1374,7 +1510,7 @@ static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
     g->b_lo = 0;
     g->b_hi = g->M.B;
     // resident launches with in-process peer-mapped inboxes, if every shard can (and the caller did not ask for two kernels)
-    bool ok = opts->launch_mode != 1 && md->kind != BB_MODEL_GENOTYPE;
+    bool ok = opts->launch_mode != 1;
 #ifndef BB_EMU
     for (int i = 0; i < n && ok; ++i)
         for (int j = 0; j < n && ok; ++j) {
@@ -1418,6 +1554,7 @@ static int group_run(bb_handle* g, int64_t n_steps) {
 #ifdef BB_EMU
         for (bb_handle* sh : g->shards) sh->req_steps += n_steps;
         rc = emu_run_group(g->shards.data(), (int)g->shards.size(), n_steps);      // the emulation steps the shards in lock step
+        if (!rc) rc = theta_sync_local(g->shards.data(), (int)g->shards.size());
         g->step = g->shards[0]->step;
         return rc;
 #endif
@@ -1425,6 +1562,7 @@ static int group_run(bb_handle* g, int64_t n_steps) {
         int rc2 = 0;                              // (wait for whatever was launched, also after an error)
         for (bb_handle* sh : g->shards) { BB_ENTER(sh); const int r = run_finish(sh); if (r && !rc2) rc2 = r; }
         if (!rc) rc = rc2;
+        if (!rc) rc = theta_sync_local(g->shards.data(), (int)g->shards.size());     // (genotype model: theta_g back from its owner)
     } else {
         // the two-kernel step of every shard with the exchanges (K moments; per-genotype gradient sums of the genotype model)
         // summed on the host: enqueue_step with host reductions in place of the RCCL all-reduces
@@ -1488,6 +1626,7 @@ extern "C" int bb_init_meanfield(bb_handle* h) {
     if (!h) return bb_fail(BB_ERR_INVALID, "null handle");
     if (!h->shards.empty()) { int rc = 0; for (bb_handle* sh : h->shards) if (!rc) rc = bb_init_meanfield(sh); h->step = 0; return rc; }
     BB_ENTER(h);
+    h->theta_stale = false;
     const int nb = (int)std::min<long long>(((h->M.D + 1) / 2 + 255) / 256, 1024);
 #ifdef BB_EMU
     emu_launch(nb, 256, 0, [&](BBCtx& cx) { bb_block_init(cx, h->M, h->S, h->o.seed, nb); });
@@ -1504,6 +1643,7 @@ extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega
     if (!h->shards.empty()) { int rc = 0; for (bb_handle* sh : h->shards) if (!rc) rc = bb_set_params(sh, mu, omega); h->step = 0; return rc; }
     BB_ENTER(h);
     int rc;
+    h->theta_stale = false;
     if ((rc = h2d(h->S.mu, mu, (size_t)h->M.D * 8, h->stream))) return rc;
     if ((rc = h2d(h->S.om, omega, (size_t)h->M.D * 8, h->stream))) return rc;
     return reset_optimizer(h);
@@ -1568,7 +1708,8 @@ static int run_enqueue(bb_handle* h, int64_t n_steps) {
         if ((rc = launch_persistent(h, n_steps))) return rc;
         done = n_steps;
         h->launches_last_run = (int)((n_steps + 4095) / 4096);
-    }
+        if (theta_partial(h)) h->theta_stale = true;         // only the owner's theta_g moved (bb_run / group_run gather it afterwards)
+    } else if (h->theta_stale && n_steps > 0 && (rc = theta_sync_comm(h))) return rc;
 #ifndef BB_EMU
     // graphs: whole steps only, starting on an even step (static ping-pong parity), elbo_every
     // pattern must repeat with the graph -> only when ELBO recording is off; no collectives inside.
@@ -1617,7 +1758,11 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     BB_ENTER(h);
     int rc = run_enqueue(h, n_steps);
     if (rc) return rc;
-    return run_finish(h);
+    if ((rc = run_finish(h))) return rc;
+#ifndef BB_EMU
+    if (h->theta_stale && h->comm) rc = theta_sync_comm(h);       // (collective: every rank ran the same bb_run)
+#endif
+    return rc;
 }
 
 extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
@@ -1819,7 +1964,8 @@ static void p2p_release(bb_handle* h) {
 static int p2p_alloc_inbox(bb_handle* h) {
     if (h->o.world_size < 2) return bb_fail(BB_ERR_INVALID, "the cross-GPU leg needs a sharded handle (world_size > 1)");
     if (h->o.world_size > BB_MAX_WORLD) return bb_fail(BB_ERR_UNSUPPORTED, "at most %d ranks", BB_MAX_WORLD);
-    if (h->M.kind == BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_UNSUPPORTED, "the genotype model has no resident launch");
+    if (h->M.kind == BB_MODEL_GENOTYPE && !h->M.geno_sorted)
+        return bb_fail(BB_ERR_UNSUPPORTED, "the genotype model's resident launch needs geno_idx in consecutive runs (shards must own whole genotypes)");
     if (h->p2p_inbox) return BB_OK;
     h->p2p_rows_bytes = p2p_rows_bytes(h);
     h->p2p_bytes = h->p2p_rows_bytes + (p2p_probe_words_off(h) + (size_t)32 * h->o.world_size) * 4;
@@ -2065,6 +2211,8 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
         }
         s->shard_lo = 0;
         s->shard_hi = h->M.B;
+        s->geno_lo = 0;
+        s->geno_hi = h->M.G;
         return rc;
     }
     memset(s, 0, sizeof *s);
@@ -2073,6 +2221,8 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->steps_done = h->step;
     s->shard_lo = h->b_lo;
     s->shard_hi = h->b_hi;
+    s->geno_lo = h->g_lo;
+    s->geno_hi = h->g_hi;
     s->bytes_sample = h->bytes_sample;
     s->bytes_update = h->bytes_update;
     s->bytes_per_step = h->bytes_update;   // theta read once when the two sweeps are fused (96 D + 4 TBR)

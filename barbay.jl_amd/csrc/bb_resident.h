@@ -65,6 +65,7 @@ struct BRLay {
     int rowmap;          // [K] ints: time-pair class k | value index v << 8 | replicate << 16 | used << 24
     int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
     int envt;            // [Ttot] ints: environment of every time point (multienv)
+    int gas;             // genotype model: [SU] w As of every mutant of the tile, summed per genotype by the theta threads
     int seg;             // BRSeg table
     int total;
     int lpb[BB_MAX_REP];
@@ -77,7 +78,7 @@ static inline long long br_tile_span(const DevModel& M, long long NB, bool globa
     long long p = 0;
     for (int r = 0; r < M.R; ++r) p = ((p + 63) & ~63ll) + NB * br_pow2_ge(M.T[r] / 2);
     if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
-    else if (M.kind == 2) p += 3 * (NB / 2 + 1);
+    else if (M.kind == 2) p += 4 * (NB / 2 + 1);          // theta of the tile's own genotypes (at most NB), theta_tilde, logtau, logsigma
     else if (M.kind == 3) p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
     else p += (NB * M.E / 2 + 1) + 3ll * M.R * (NB * M.E / 2 + 1);
     if (globals) p += 2 * (M.nt1 / 2 + 1);
@@ -85,7 +86,7 @@ static inline long long br_tile_span(const DevModel& M, long long NB, bool globa
 }
 
 static inline bool br_eligible(const DevModel& M) {
-    if (M.kind == 2) return false;                 // (genotype model: its theta block needs a second exchange)
+    if (M.kind == 2 && !M.geno_sorted) return false;   // (genotype model: tiles must own whole genotypes, see br_tile_geno)
     if (M.quirk || M.Ttot > 64) return false;
     for (int r = 0; r < M.R; ++r) if ((M.T[r] & 1) || M.T[r] > BR_MAXT) return false;
     if (M.blk_lo[BK_L] & 1) return false;
@@ -130,6 +131,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     Y.iG = o;      o += M.Ttot;
     Y.csum = o;    o += BB_MAX_REP;
     Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
+    Y.gas = o;     o += M.kind == 2 ? Y.SU : 0;
     Y.seg = o;     o += BR_SEG_DOUBLES * (BB_MAX_SEG + 1);
     L.seg = Y.seg;
     o = (o + 1) & ~1;
@@ -193,9 +195,25 @@ BB_DEV BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
     return t;
 }
 
+// Genotype model: the tiles' cuts come from a host-built table and fall on genotype boundaries (geno_idx is non-decreasing), so
+// that a tile holds ALL mutants of the genotypes [tile_g[i], tile_g[i + 1]) it owns: d/dtheta_g = sum over the genotype's mutants
+// of w As is then a sum inside the tile, and theta_g is sampled, staged and updated by that tile alone
+// (/root/reference/src/model_fitness_normal_hierarchical_genotypes.jl:209-243: s_eff = theta[geno] + exp(logtau) theta_tilde).
+BB_DEV BBTile br_tile_geno(const DevModel& M, const DevState& S, int block, int NB) {
+    BBTile t;
+    t.NB = NB;
+    t.b0 = S.tile_b[block];
+    t.nbt = (int)(S.tile_b[block + 1] - t.b0);
+    long long ns = M.nn - t.b0;
+    t.nshift = (int)(ns < 0 ? 0 : (ns > t.nbt ? t.nbt : ns));
+    t.m0 = t.b0 + t.nshift - M.nn;
+    t.nmt = t.nbt - t.nshift;
+    return t;
+}
+
 // ---- segment table of a tile in the padded thread-index space (one thread) --------------------------------------
 template <int KIND>
-BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTile& t, bool globals) {
+BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTile& t, bool globals, int g0 = 0, int g1 = 0) {
     int n = 0, cur = 0;
     auto add = [&](int blk, int kind, long long lo, long long cnt, int ldsoff, int r, int lpb, int T) {
         if (cnt <= 0) return;
@@ -210,7 +228,12 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
     };
     for (int r = 0; r < M.R; ++r)
         add(BK_L, SK_L, M.off_l[r] + t.b0 * M.T[r], (long long)t.nbt * M.T[r], Y.zr0[r], r, Y.lpb[r], M.T[r]);
-    if (t.nmt > 0) {
+    if (KIND == 2) {   // theta of the tile's genotypes (stage table 3, index = genotype - g0), then per mutant tt / lt / ls
+        add(BK_S, SK_TH_R, M.blk_lo[BK_S] + g0, g1 - g0, 0, 0, 0, 0);
+        add(BK_TT, SK_TT_R, M.blk_lo[BK_TT] + t.m0, t.nmt, 0, 0, 0, M.T[0]);
+        add(BK_LT, SK_LT_R, M.blk_lo[BK_LT] + t.m0, t.nmt, 0, 0, 0, M.T[0]);
+        add(BK_LS, SK_LS_R, M.blk_lo[BK_LS] + t.m0, t.nmt, 0, 0, 0, M.T[0]);
+    } else if (t.nmt > 0) {
         if (KIND == 0 || KIND == 1) {
             const int E = KIND == 1 ? M.E : 1;
             add(BK_S, SK_S, M.blk_lo[BK_S] + t.m0 * E, (long long)t.nmt * E, 0, 0, 0, M.T[0]);
@@ -240,13 +263,14 @@ template <int KIND, int P>
 BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, BRSt<P>* stv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
-    const BBTile t = br_tile(M, A, cx.block, NB);
+    const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
+    const int g0 = KIND == 2 ? S.tile_g[cx.block] : 0, g1 = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     BRSeg* sg = (BRSeg*)(lds + Y.seg);
     int* li = (int*)(lds + L.misc);
     const int KK = M.K + 2 * M.nt1;
     BB_PASS(cx, tid) {
         // li[1] = exchange ok word; it starts at 0 ("leave") while an earlier launch's timeout is unacknowledged by the host
-        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = t.nbt; }
+        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0, g0, g1); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = t.nbt; }
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
         for (int i = tid; i < 2 * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
         for (int i = tid; i < 2 * Y.nst * Y.SU; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
@@ -298,7 +322,8 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                             // stage index of the unit (ml [, r] [, e]) -- fitness: ml; multienv: ml E + e; replicate: r NB + ml;
                             // multienv_replicate: (r NB + ml) E + e -- for the differences t0-1, t0, t0+1 (environment of t + 1)
                             const int base = KIND >= 3 ? (s.r * t.NB + ml) * E : ml * E;
-                            st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : 0;
+                            // (genotype model: unit ml, theta index = its genotype's position among the tile's own = ml - thoff)
+                            st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : (KIND == 2 ? ml - (M.geno_idx[t.m0 + ml] - g0) : 0);
                             for (int d = 0; d < 3; ++d) {
                                 const int tt = t0 - 1 + d;
                                 const int e = (E > 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
@@ -316,7 +341,18 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                     meta |= (a0 ? BRM_A0 : 0) | (a1 ? BRM_A1 : 0) | BRM_VALID;
                     st.zoff[k] = s.ldsoff + (int)(i0 - s.lo);      // stage index of latent 0 (may sit one before the segment: never stored)
                     st.thoff[k] = s.ldsoff;                          // (hierarchical: r NB E_; the theta of unit j is j - thoff)
-                    if (s.kind < SK_GS) {
+                    if (KIND == 2 && s.kind == SK_TH_R) {
+                        // theta of genotype g: its mutants are the consecutive local units [first, first + n) -- uo[x] = first | n << 16
+                        for (int x = 0; x < 2; ++x) {
+                            const long long g = g0 + (i0 - s.lo) + x;
+                            int first = 0, n = 0;
+                            if (g >= g0 && g < g1) {
+                                n = M.geno_ptr[g + 1] - M.geno_ptr[g];
+                                if (n > 0) first = (int)(M.geno_mem[M.geno_ptr[g]] - t.m0);
+                            }
+                            st.uo[k][x] = first | (n << 16);
+                        }
+                    } else if (s.kind < SK_GS) {
                         // unit (ml, e) of latent x: index j = (i0 - lo) + x = ml * E + e inside the segment; its barcode's local index
                         int env = 0;
                         for (int x = 0; x < 2; ++x) {
@@ -324,7 +360,9 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                             if (j < 0) j = 0;
                             const int ml = j / E, e = j - ml * E;
                             st.uo[k][x] = t.nshift + ml;
-                            env |= e << (8 * x);
+                            // (genotype model, E == 1: the unit's theta index instead of its environment, 16 bits each)
+                            if (KIND == 2) env |= ((j < t.nmt ? M.geno_idx[t.m0 + j] - g0 : 0) & 0xffff) << (16 * x);
+                            else env |= e << (8 * x);
                         }
                         st.uo[k][2] = env;
                         st.pt[k] = s.r;
@@ -415,7 +453,7 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             BR_SCHED_FENCE();
             // loglambda: lambda = e^z; logsigma_bc: precision w = e^{-2 z}; (others: unused)
             const int kd = st.meta[k] & 15;
-            const double f = (kd == SK_LS_E || (KIND >= 3 && kd == SK_LS_R)) ? -2.0 : 1.0;      // logtau: e^{logtau}
+            const double f = (kd == SK_LS_E || (KIND >= 2 && kd == SK_LS_R)) ? -2.0 : 1.0;      // logtau: e^{logtau}
             st.lam[k] = bb_d2{bb_exp(f * st.z[k].x), bb_exp(f * st.z[k].y)};
             BR_SCHED_FENCE();
         }
@@ -497,7 +535,7 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
             cv[6] += st.lam[k].y;
             if (mut) {
                 double sm, sn, wm, wn;
-                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 3 ? st.thoff[k] : 0, &sm, &wm);
+                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &sm, &wm);
                 if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
                 else { sn = sm; wn = wm; }
                 dm -= sm; dn -= sn;
@@ -622,7 +660,7 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
     double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
     if (mut) {
         double sp, sm, sn;
-        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 3 ? st.thoff[k] : 0, &sm, &wm);
+        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &sm, &wm);
         if (KIND == 1 || KIND == 4) {
             br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], KIND >= 3 ? st.thoff[k] : 0, &sp, &wp);
             br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
@@ -651,6 +689,10 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     //  is bound by the SIMDs' total VALU work, not by the unit waves; C2 15.3 -> 15.5 us per step, C3 unchanged.)
     BB_STAMP_WAVE(cx, S, A, 2);
     const double* zbuf = lds + Y.zl + buf * Y.NBT;
+    // Genotype model: two passes.  Pass 0 updates everything but theta, and the theta_tilde thread of every mutant leaves w As in
+    // LDS; after one more barrier the theta threads add up their genotypes' members (consecutive units of this tile) and update.
+    for (int pass = 0; pass < (KIND == 2 ? 2 : 1); ++pass) {
+    if (pass) BB_SYNC(cx);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
         double* hs_m = nullptr;
@@ -664,6 +706,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             const int meta = st.meta[k];
             if (!(meta & BRM_VALID)) continue;
             const int kind = meta & 15;
+            if (KIND == 2 && (kind == SK_TH_R) != (pass == 1)) continue;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
             const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
             // prior of the pair's two latents: Vector form from the segment (LDS, one address per wave mostly), Matrix form per element
@@ -678,6 +721,17 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 const double* zb = zbuf + st.zoff[k];
                 z0 = zb[0]; z1 = zb[1];
                 br_l_grad<KIND>(lds, Y, st, k, buf, &g0, &g1);
+            } else if (KIND == 2 && kind == SK_TH_R) {
+                const double* stg = lds + buf * Y.SU;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    if (!(x ? a1 : a0)) continue;
+                    const int first = st.uo[k][x] & 0xffff, n = st.uo[k][x] >> 16;
+                    double acc = 0.0;
+                    for (int i = 0; i < n; ++i) acc += lds[Y.gas + first + i];
+                    (x ? g1 : g0) = acc;
+                    (x ? z1 : z0) = stg[Y.st[3] + st.zoff[k] + x];
+                }
             } else if (kind < SK_GS) {
                 // Unit latents.  Per unit u = (mutant [, replicate] [, environment]) the sums over the time steps that use it,
                 //   As = w sum r,  Qs = w sum r^2 - n,  r = dl - s_eff - c_t,
@@ -691,7 +745,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 for (int x = 0; x < 2; ++x) {
                     if (!(x ? a1 : a0)) continue;
                     const int j = st.zoff[k] + x;                      // stage index of the latent
-                    const int e = (st.uo[k][2] >> (8 * x)) & 255, bl = st.uo[k][x];
+                    const int e = KIND == 2 ? 0 : (st.uo[k][2] >> (8 * x)) & 255, bl = st.uo[k][x];
                     zx[x] = stg[Y.st[br_stage_raw<KIND>(kind)] + j];
                     // replicates whose rows the latent's gradient sums over: its own; theta: all of them
                     const bool is_th = KIND >= 3 && kind == SK_TH_R;
@@ -700,7 +754,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                     for (int r = r0; r < r1; ++r) {
                         // stage index of the unit (bl's mutant, replicate r, environment e) and its s_eff, w
                         const int o = is_th ? (r * NBs + (j / E)) * E + e : j;
-                        const int th = KIND <= 1 ? 0 : (is_th ? r * NBs * E : st.thoff[k]);
+                        const int th = KIND <= 1 ? 0 : (KIND == 2 ? j - ((st.uo[k][2] >> (16 * x)) & 0xffff) : (is_th ? r * NBs * E : st.thoff[k]));
                         double sv, wv;
                         br_unit_sw<KIND>(lds, Y, buf, o, th, &sv, &wv);
                         const int T = TT ? TT : M.T[r], tc = KIND <= 1 ? 0 : M.tcum[r];
@@ -727,7 +781,10 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                         if (KIND <= 1) acc = kind == SK_S ? wv * As : wv * Qs - (double)nn;
                         else if (is_th) acc += wv * As;
                         else if (kind == SK_LS_R) acc = wv * Qs - (double)nn;
-                        else if (kind == SK_TT_R) acc = wv * As * stg[Y.st[1] + j];                          // e^{logtau}
+                        else if (kind == SK_TT_R) {
+                            acc = wv * As * stg[Y.st[1] + j];                                                // e^{logtau}
+                            if (KIND == 2) lds[Y.gas + j] = wv * As;                                         // d/ds_eff: its genotype's theta sums these
+                        }
                         else acc = wv * As * stg[Y.st[1] + j] * stg[Y.st[0] + j];                            // logtau: e^{logtau} theta_tilde
                     }
                     gx[x] = acc;
@@ -766,6 +823,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             }
             if (hs_m) { bb_store_pair(hs_m, st.i0[k], a0, a1, nhm); bb_store_pair(hs_o, st.i0[k], a0, a1, nho); }
         }
+    }
     }
     BB_STAMP_WAVE(cx, S, A, 3);
     BB_STAMP(cx, S, 28);

@@ -46,6 +46,8 @@ struct DevModel {
     const int* geno_idx;              // device [nb]
     const int* geno_ptr;              // device [G+1]   CSR over genotypes
     const int* geno_mem;              // device [nb]    mutant indices grouped by genotype
+    int geno_sorted;                  // 1 = geno_idx is non-decreasing: a genotype's mutants are consecutive, so tiles / shards cut at genotype
+                                      // boundaries own their genotypes' theta outright (the resident launch of the genotype model needs it)
     const unsigned* counts;           // device, uint32, same indexing as loglambda minus blk_lo
 };
 
@@ -73,6 +75,8 @@ struct DevState {
     double *prow;                     // [nblk][K + 2 nt1] rows of the tiles (persistent launch)
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
+    const long long *tile_b;          // genotype model, k_res: [tiles + 1] first barcode of every tile (cuts fall on genotype boundaries)
+    const int *tile_g;                // genotype model, k_res: [tiles + 1] first genotype every tile owns
     unsigned long long *stamps;       // [nblk + 8][32] s_memtime stamps, then [nblk + 8][4][16] per-wave stamps (diagnostic build -DBB_STAMPS only)
     // cross-GPU leg of the resident launch's exchange (bb_p2p_*): every rank owns an INBOX -- group rows
     // [2 parity][world][8 groups][K + 2 nt1] and their ready words [2][world][8] (one 128-B line each) -- in

@@ -91,7 +91,8 @@ def gather_posterior(engine, kind: str, n_neutral: int, n_bc: int, n_time: Seque
     mean, sigma = engine.posterior()
     st = engine.stats()
     layout: Dict[str, Tuple[int, int]] = {n: (lo, hi) for n, lo, hi in engine.layout()}
-    ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env)
+    ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env,
+                       geno_range=(int(st["geno_lo"]), int(st["geno_hi"])) if kind == "genotype" else None)
     parts = [None] * dist.get_world_size()
     dist.all_gather_object(parts, (ix, mean[ix], sigma[ix]))
     for i, m, s in parts:

@@ -79,8 +79,12 @@ def _multi_tensor(df: pd.DataFrame, ids, reps, id_col, time_col, count_col, rep_
 
 def data_to_arrays(data: pd.DataFrame, *, id_col="barcode", time_col="time", count_col="count", neutral_col="neutral",
                    rep_col: Optional[str] = None, env_col: Optional[str] = None,
-                   genotype_col: Optional[str] = None) -> DataArrays:
-    """Tidy frame -> model inputs; neutrals first then mutants (src/utils.jl:431), totals = row sums (:432)."""
+                   genotype_col: Optional[str] = None, group_genotypes: bool = False) -> DataArrays:
+    """Tidy frame -> model inputs; neutrals first then mutants (src/utils.jl:431), totals = row sums (:432).
+
+    group_genotypes (not in the reference): order the mutants by genotype (stable, genotypes in order of first appearance), so
+    that a genotype's barcodes are consecutive.  The results are keyed by barcode id, so the order is the caller's to choose;
+    with it the engine's resident launch and its genotype-aligned sharding apply to genotype_fitness_normal."""
     neu = _neutral_mask(data, neutral_col)
     timepoints = sorted(data[time_col].unique())                                   # _extract_timepoints :81-89
     if rep_col is None:                                                            # :409-448
@@ -136,6 +140,17 @@ def data_to_arrays(data: pd.DataFrame, *, id_col="barcode", time_col="time", cou
         m = dict(zip(data[id_col], data[genotype_col]))
         genotypes = [m[b] for b in bc_ids]
         n_geno = len(set(genotypes))
+        if group_genotypes:
+            if rep_col is not None:
+                raise ValueError("group_genotypes applies to the single-replicate genotype model")
+            first = {}
+            for gname in genotypes:
+                first.setdefault(gname, len(first))
+            order = np.argsort(np.asarray([first[gname] for gname in genotypes]), kind="stable")
+            nn = len(neutral_ids)
+            R = np.concatenate([R[:, :nn], R[:, nn:][:, order]], axis=1)
+            bc_ids = [bc_ids[i] for i in order]
+            genotypes = [genotypes[i] for i in order]
     return DataArrays(R, n_t, len(neutral_ids), len(bc_ids), list(bc_ids), list(neutral_ids), envs, n_env, n_rep,
                       n_time, genotypes, n_geno)
 

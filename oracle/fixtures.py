@@ -78,8 +78,9 @@ def load(name: str, **priors) -> ModelSpec:
 
 
 def synthetic(kind: str, B: int, T, n_rep: int = 1, n_env: int = 1, n_geno: int = 0, seed: int = 0,
-              n_neutral: int | None = None, depth_per_bc: int = 200, **priors) -> ModelSpec:
-    """Small seeded synthetic spec for oracle-vs-engine tests (numpy default_rng)."""
+              n_neutral: int | None = None, depth_per_bc: int = 200, geno_runs: bool = False, **priors) -> ModelSpec:
+    """Small seeded synthetic spec for oracle-vs-engine tests (numpy default_rng).  geno_runs: the genotype model's mutants
+    come grouped by genotype (non-decreasing geno_idx, runs of random length), as a host that sorts its barcodes hands them over."""
     g = np.random.default_rng(seed)
     nn = max(1, B // 5) if n_neutral is None else n_neutral
     nb = B - nn
@@ -111,6 +112,7 @@ def synthetic(kind: str, B: int, T, n_rep: int = 1, n_env: int = 1, n_geno: int 
             kw["env_idx"].append(flat[o:o + Ts[r]])
             o += Ts[r]
     if kind == "genotype":
-        kw["geno_idx"] = _first_idx(list(g.integers(0, max(1, n_geno), nb)))
+        gi = list(g.integers(0, max(1, n_geno), nb))
+        kw["geno_idx"] = _first_idx(sorted(gi) if geno_runs else gi)
     return ModelSpec(kind=kind, counts=counts, totals=[c.sum(axis=1) for c in counts], n_neutral=nn,
                      n_bc=nb, priors=priors, **kw)

@@ -20,12 +20,14 @@ os.environ["BB_TUNE_NB"] = "16"; os.environ["BB_TUNE_NTHR"] = "512"
 c.case_p2p_resident(lib, "fitness_multi_tile", 3, steps=5)
 c.case_p2p_resident(lib, "multienv_replicate", 2, steps=5)
 c.case_p2p_resident(lib, "multienv_T8", 2, steps=5)                       # k_res (bb_resident.h), sharded
+c.case_p2p_resident(lib, "genotype_runs", 3, steps=5)                     # k_res, genotype model: tiles / shards own whole genotypes
 del os.environ["BB_TUNE_NB"]; del os.environ["BB_TUNE_NTHR"]
 c.case_persistent_equals_two_kernel(lib, "replicate_ragged")
 c.case_persistent_equals_two_kernel(lib, "fitness_T6", expect_kernel=2)   # k_res: LPB 4 with an idle lane per barcode
 c.case_persistent_equals_two_kernel(lib, "multienv_T8", expect_kernel=2)
 c.case_persistent_equals_two_kernel(lib, "replicate_R3", expect_kernel=2)           # k_res, hierarchical, ragged
 c.case_persistent_equals_two_kernel(lib, "multienv_replicate_R3", expect_kernel=2)
+c.case_persistent_equals_two_kernel(lib, "genotype_T8", expect_kernel=2)
 os.environ["BB_TUNE_NB"] = "40"; os.environ["BB_TUNE_NTHR"] = "128"        # two pair slots per thread, tiles ending inside a wave
 c.case_persistent_equals_two_kernel(lib, "fitness_T4", expect_kernel=2)
 del os.environ["BB_TUNE_NB"]; del os.environ["BB_TUNE_NTHR"]

@@ -1,6 +1,9 @@
 """CPU tests of the HIP block programs through their sequential host emulation (g++ -DBB_EMU build of
 barbay.jl_amd/csrc/bb_engine.hip).  Same cases as the GPU parity tests; covers the host logic of the
 engine (layout, validation, stepping, sharding) where no GPU exists."""
+import dataclasses
+
+import numpy as np
 import pytest
 
 import _cases as c
@@ -96,6 +99,57 @@ def test_owner_computes_launch_smaller_leader_tiles(emu_lib, monkeypatch, lead):
     c.case_persistent_equals_two_kernel(emu_lib, "fitness_T6", expect_kernel=2)
     c.case_persistent_equals_two_kernel(emu_lib, "multienv_T8", expect_kernel=2)
     c.case_p2p_resident(emu_lib, "fitness_T6", 2)
+
+
+@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
+def test_owner_computes_launch_genotype(emu_lib, name):
+    """Genotype model under k_res: mutants grouped by genotype, tiles cut at genotype boundaries own their genotypes' theta
+    (sample, stage, d/dtheta_g = sum over the genotype's mutants inside the tile, update) -- against the two-kernel step with
+    its grid-wide per-genotype sums, and against the literal oracle."""
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
+
+
+@pytest.mark.parametrize("nb,nthr,lead", [(24, 128, 100), (40, 256, 65), (64, 512, 50), (100, 1024, 100), (30, 64, 100)])
+def test_owner_computes_launch_genotype_geometries(emu_lib, monkeypatch, nb, nthr, lead):
+    """several pair slots per thread, theta pairs split between two tiles, smaller leader tiles, the neutral / mutant boundary
+    inside a tile"""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_LEAD", str(lead))
+    c.case_persistent_equals_two_kernel(emu_lib, "genotype_runs", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(emu_lib, "genotype_T8", expect_kernel=2)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_computes_launch_genotype_sharded(emu_lib, monkeypatch, world):
+    """shards cut at genotype boundaries: every rank owns its genotypes' theta, no second exchange; theta comes back from its
+    owner at the end of the run"""
+    monkeypatch.setenv("BB_TUNE_NB", "24")
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    c.case_p2p_resident(emu_lib, "genotype_runs", world)
+    c.case_p2p_resident(emu_lib, "genotype_T8", world)
+    c.case_multi_device_handle(emu_lib, "genotype_runs", n=world)
+
+
+def test_genotype_empty_genotypes_and_unsorted(emu_lib, monkeypatch):
+    """genotypes without mutants (theta_g feels its prior only) ride with the tile before them; geno_idx that is not in
+    consecutive runs keeps the two-kernel step"""
+    import barbay_jl_amd as bb
+    from conftest import make_engine
+    sp = c.synth("genotype_runs", seed=6)
+    gi = np.asarray(sp.geno_idx).copy()
+    gi = gi + 2 * (gi >= 7) + 2 * (gi >= 20)            # genotypes 7, 8, 22, 23 are empty; the count stays even
+    sp = dataclasses.replace(sp, geno_idx=gi)
+    outs = []
+    for mode in (1, 2):
+        with make_engine(sp, emu_lib, seed=13, window=6, resum_every=1, launch_mode=mode) as e:
+            e.run(11)
+            outs.append(e.get_params())
+            if mode == 2:
+                assert e.stats()["resident_kernel"] == 2
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-11 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-11
+    with pytest.raises(bb.BarBayHipError, match="consecutive runs"):
+        make_engine(c.synth("genotype"), emu_lib, launch_mode=2)
 
 
 def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):

@@ -62,7 +62,7 @@ def _worker(rank, world, port, case, steps, p2p, out_dir):
 
 
 @pytest.mark.parametrize("p2p", [False, True], ids=["rccl", "xgmi_inbox"])
-@pytest.mark.parametrize("case", ["fitness_multi_tile", "replicate_ragged"])
+@pytest.mark.parametrize("case", ["fitness_multi_tile", "replicate_ragged", "genotype_runs"])
 def test_sharded_over_real_peers(hip_lib, tmp_path, monkeypatch, case, p2p):
     if _n_gpus() < 2:
         pytest.skip("needs >= 2 GPUs")

@@ -218,7 +218,42 @@ def test_owner_computes_launch_geometries(hip_lib, monkeypatch, nb, nthr):
     c.case_persistent_equals_two_kernel(hip_lib, "multienv_T8", expect_kernel=2)
 
 
-@pytest.mark.parametrize("name,n", [("fitness_multi_tile", 2), ("fitness_T6", 3), ("multienv_T8", 2), ("replicate_ragged", 2)])
+@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
+def test_owner_computes_launch_genotype(hip_lib, name):
+    """Genotype model under k_res (mutants grouped by genotype, tiles own whole genotypes and their theta): same arithmetic as
+    the two-kernel step with its grid-wide per-genotype sums, and as the literal oracle's optimiser trajectory."""
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
+
+
+@pytest.mark.parametrize("nb,nthr,lead", [(24, 128, 100), (40, 256, 65), (64, 512, 50), (100, 1024, 100)])
+def test_owner_computes_launch_genotype_geometries(hip_lib, monkeypatch, nb, nthr, lead):
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_LEAD", str(lead))
+    c.case_persistent_equals_two_kernel(hip_lib, "genotype_runs", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(hip_lib, "genotype_T8", expect_kernel=2)
+
+
+@pytest.mark.parametrize("B,G", [(25_000, 626), (50_000, 1_250)])
+def test_genotype_resident_at_shard_size(hip_lib, B, G):
+    """BASELINE config 5 as one rank of its 8-GPU run sees it (200 000 / 8 barcodes, 5 000 / 8 genotypes -- one genotype more:
+    a standalone problem needs an even count for loglambda to start at an even index), and about the largest genotype problem
+    whose state fits one GPU's registers: the resident launch against the two-kernel step."""
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import port
+    sp = port.spec_from_workload(synth.genotype_fitness_normal(B, 8, G, 45))
+    outs = []
+    for mode in (1, 2):
+        with make_engine(sp, hip_lib, seed=7, launch_mode=mode) as e:
+            e.run(61)
+            outs.append(e.get_params())
+            if mode == 2:
+                assert e.stats()["resident_kernel"] == 2
+    assert np.all(np.isfinite(outs[1][0])) and np.abs(outs[0][0] - outs[1][0]).max() < 1e-8 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-8
+
+
+@pytest.mark.parametrize("name,n", [("fitness_multi_tile", 2), ("fitness_T6", 3), ("multienv_T8", 2), ("replicate_ragged", 2), ("genotype_runs", 2)])
 def test_multi_device_handle(hip_lib, monkeypatch, name, n):
     """bb_advi_opts.n_devices: one handle, one host thread, n shards -- here all on device 0, their resident
     launches co-resident, inboxes wired in process -- against the unsharded run."""

@@ -47,6 +47,24 @@ def test_multienv_and_genotype_arrays():
     assert g.genotypes == [want[b] for b in g.bc_ids] and g.n_geno == 1                    # test/utils_tests.jl:372-376
 
 
+def test_group_genotypes_orders_mutants_by_genotype():
+    """data_to_arrays(group_genotypes=True): a genotype's barcodes become consecutive (what the engine's resident launch and
+    genotype-aligned sharding of genotype_fitness_normal need); every barcode keeps its own counts."""
+    df = load("data004_multigen").copy()
+    ids = sorted(df.loc[df.neutral.astype(str).str.lower() != "true", "barcode"].unique())
+    lab = {b: f"g{(7 * i) % 3}" for i, b in enumerate(ids)}                 # three interleaved genotypes
+    df["genotype"] = [lab.get(b, "neutral") for b in df.barcode]
+    a = bb.utils.data_to_arrays(df, genotype_col="genotype")
+    g = bb.utils.data_to_arrays(df, genotype_col="genotype", group_genotypes=True)
+    assert sorted(g.bc_ids) == sorted(a.bc_ids) and g.n_geno == a.n_geno == 3
+    runs = [x for i, x in enumerate(g.genotypes) if i == 0 or x != g.genotypes[i - 1]]
+    assert len(runs) == 3 and runs == list(dict.fromkeys(a.genotypes))      # consecutive runs, genotypes in order of first appearance
+    nn = a.n_neutral
+    col = {b: a.bc_count[:, nn + i] for i, b in enumerate(a.bc_ids)}
+    assert all((g.bc_count[:, nn + i] == col[b]).all() for i, b in enumerate(g.bc_ids))
+    assert (g.bc_count[:, :nn] == a.bc_count[:, :nn]).all() and (g.bc_total == a.bc_total).all()
+
+
 def test_missing_timepoint_is_an_error():
     df = load("data001_single")
     with pytest.raises(bb.BarBayError, match="Not all"):
