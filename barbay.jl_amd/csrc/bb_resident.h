@@ -890,11 +890,14 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
     int* ok_slot = (int*)(br_smem + Yp->L.misc) + 1;
     const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
     const unsigned long long step0 = c0 > c1 ? c0 : c1;
+    BB_STAMP_RT(cx, S, 2);
     br_prologue<KIND, P>(cx, M, S, A, Y, NB, &st);
+    BB_STAMP_RT(cx, S, 3);
     const bool dead = *ok_slot == 0;
     int done = 0;
     if (!dead) {
         br_draw_ahead<P>(cx, A, Y, &st, step0);
+        BB_STAMP_RT(cx, S, 4);
         for (; done < nsteps; ++done) {
             const unsigned long long step = step0 + (unsigned long long)done;
             const int buf = (int)(step & 1);
@@ -907,6 +910,8 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
             br_update<KIND, P, TT>(cx, M, S, A, Y, &st, step, buf, NB);
         }
     }
+    BB_STAMP_RT(cx, S, 5);
     br_epilogue<P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
+    BB_STAMP_RT(cx, S, 6);
 }
 #endif

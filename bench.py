@@ -148,7 +148,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()              # (the barrier is itself GPU work)
 
     if exchange == "p2p":
         # first resident launches under a vote: a rank that times out must not leave the others behind on another path
