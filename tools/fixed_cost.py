@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: fixed cost of a bb_run (kernel prologue / epilogue + host) -- kernel time (HIP events) and wall time for n steps."""
+"""Diagnostic: fixed cost of a bb_run (kernel prologue / epilogue + host) -- kernel time (HIP events) and wall time for n steps.
+(Tried on the host side and dropped, gpurun_out r02e: polling hipEventQuery instead of hipStreamSynchronize -- no change; the
+run's timing events attached to the launch with hipExtLaunchKernel -- event time -3 us, wall time +8 us.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,7 +9,9 @@ import numpy as np
 import barbay_jl_amd as bb
 from barbay_jl_amd import synth
 wl = synth.fitness_normal(50000, 8, 42)
-e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42)
+from barbay_jl_amd import _capi
+_lib = _capi.load_library(os.environ["LIB"]) if os.environ.get("LIB") else None        # (an A/B build: tools/xp.py build NAME)
+e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, _lib=_lib)
 e.run(1200)
 for n in (1, 2, 5, 10, 20, 40, 80):
     ks, ws = [], []
@@ -17,8 +21,7 @@ for n in (1, 2, 5, 10, 20, 40, 80):
 
 # where a launch's fixed time goes: wall-clock stamps (100 MHz) of the -DBB_STAMPS build (python tools/xp.py build base)
 st_lib = os.path.join(ROOT, "barbay.jl_amd", "lib", "ab", "base_st.so")
-if os.path.exists(st_lib):
-    from barbay_jl_amd import _capi
+if os.path.exists(st_lib) and not os.environ.get("NO_STAMPS"):
     e.close()
     e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, _lib=_capi.load_library(st_lib))
     e.run(1200)
