@@ -21,14 +21,15 @@
 // Three workgroup barriers per step (+ the leaders' two).  LDS tables that a later phase of the SAME step still reads
 // while fast waves already write the next step's values (z, unit stages) are double-buffered by step parity.
 //
-// Lane mapping: every loglambda segment (one per replicate) starts at a wave boundary; LPB = pow2 >= T/2 lanes per
-// barcode, lane = bl * LPB + k owns (b, 2k), (b, 2k+1); k >= T/2 idles (T = 6: one lane in four).  All lanes of a wave with
-// equal lane % LPB feed the same moment rows, so the wave-level sum is a butterfly over the upper lane bits.  Unit pairs
-// follow, flat.  Needs: every T_r even and <= 16, the loglambda block starting at an even flat index (pairs then never
-// straddle barcodes), not the ragged-method quirk; other shapes keep k_persist.
+// Lane mapping: every loglambda segment (one per replicate) starts at a wave boundary; LPB = T/2 lanes per barcode,
+// lane = bl * LPB + k owns (b, 2k), (b, 2k+1).  Their moment contributions go to LDS transposed (one column entry per lane)
+// and are summed by column walks of stride LPB.  Unit pairs follow, flat.  Needs: every T_r even and <= 16, the loglambda
+// block starting at an even flat index (pairs then never straddle barcodes), not the ragged-method quirk; other shapes keep
+// k_persist.
 //
 // Written, like bb_persist.h, as passes over an explicit per-thread state so that the host emulation (tests) runs the
-// same source; the only wave-level operation (the butterfly) has an emulation twin that adds the same numbers.
+// same source; the wave-level operations (a DPP row sum, the LDS-DMA prefetch) have emulation twins that add / move the same
+// numbers.
 #pragma once
 #include "bb_persist.h"
 
@@ -71,12 +72,14 @@ struct BRLay {
     int lpb[BB_MAX_REP];
 };
 
-static inline int br_pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+// lanes per barcode of a loglambda segment: one per pair of time points.  (Any count works: the moment contributions are summed
+// by column walks over the segment's lanes, stride LPB, not by a butterfly over lane bits -- T = 6 used to idle one lane in four.)
+static inline int br_lpb(int T) { return T / 2; }
 
 // padded thread-index span of a tile: loglambda segments wave-aligned, LPB lanes per barcode, then the unit pairs
 static inline long long br_tile_span(const DevModel& M, long long NB, bool globals) {
     long long p = 0;
-    for (int r = 0; r < M.R; ++r) p = ((p + 63) & ~63ll) + NB * br_pow2_ge(M.T[r] / 2);
+    for (int r = 0; r < M.R; ++r) p = ((p + 63) & ~63ll) + NB * br_lpb(M.T[r]);
     if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
     else if (M.kind == 2) p += 4 * (NB / 2 + 1);          // theta of the tile's own genotypes (at most NB), theta_tilde, logtau, logsigma
     else if (M.kind == 3) p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
@@ -104,7 +107,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     const int KK = M.K + 2 * M.nt1;
     int o = 0;
     int lmax = 1;
-    for (int r = 0; r < BB_MAX_REP; ++r) { Y.lpb[r] = r < M.R ? br_pow2_ge(M.T[r] / 2) : 1; if (Y.lpb[r] > lmax) lmax = Y.lpb[r]; }
+    for (int r = 0; r < BB_MAX_REP; ++r) { Y.lpb[r] = r < M.R ? br_lpb(M.T[r]) : 1; if (Y.lpb[r] > lmax) lmax = Y.lpb[r]; }
     BBLds& L = Y.L;
     L = BBLds{};
     Y.NBT = 0;
@@ -443,6 +446,12 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
+            // a pair slot that no lane of this wave uses (the tail of the tile's last slot) costs nothing
+#ifdef BB_EMU
+            if (!(st.meta[k] & BRM_VALID)) continue;
+#else
+            if (P > 1 && __builtin_amdgcn_ballot_w64((st.meta[k] & BRM_VALID) != 0) == 0ull) continue;
+#endif
             const bb_d2 e = ((const bb_d2*)(lds + Y.eps))[k * cx.nthr + tid];
             double sp0, sg0, sp1, sg1;
             bb_softplus_sigmoid(st.om[k].x, &sp0, &sg0);
