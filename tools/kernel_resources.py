@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: registers / spills / scratch of every kernel instance in the built library (from the code object's notes).
-   python tools/kernel_resources.py [substring]"""
+   python tools/kernel_resources.py [substring]      (LIB=path: another build)"""
 import os
 import re
 import struct
@@ -9,7 +9,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = os.path.join(ROOT, "barbay.jl_amd", "lib", "libbarbay_hip.so")
+lib = os.environ.get("LIB") or os.path.join(ROOT, "barbay.jl_amd", "lib", "libbarbay_hip.so")
 data = open(lib, "rb").read()
 o = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
 n = struct.unpack_from("<Q", data, o + 24)[0]
