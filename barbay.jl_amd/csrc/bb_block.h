@@ -20,6 +20,7 @@
 #pragma once
 #include "bb_types.h"
 #include <math.h>
+#include <string.h>
 
 #ifdef BB_EMU
 #define BB_DEV static inline
@@ -85,9 +86,6 @@ template <bool COH> BB_DEV void bb_st(double* p, double v) {
 #endif
     *p = v;
 }
-#ifndef BB_GUARD
-#define BB_GUARD 0x1p24    /* running-window cancellation guard of bb_opt_apply: re-add an element exactly beyond this ratio */
-#endif
 #define BB_MAX_SEG (4 + 4 * BB_MAX_REP)
 
 // ------------------------------------------------------------------------------------------------
@@ -341,30 +339,60 @@ BB_DEV BBSlot bb_slot_of(const RunArgs& A, unsigned long long step) {
     BBSlot w;
     w.slot = A.opt == 0 ? (int)(step % (unsigned long long)A.W) : 0;
     // exact re-add of the window: every step (resum_every == 1: the reference's arithmetic), every resum_every steps, or
-    // (resum_every == 0, the default) once per window while the gradients still fall by orders of magnitude -- the first ten
-    // windows -- and once per ten windows afterwards: a re-add reads the whole window (32 D W bytes), at one per window that is
-    // a third of the step's HBM traffic again (C2: 2.9 us of 21 us per step)
-    const unsigned long long W = (unsigned long long)A.W;
-    w.resum = A.opt == 0 && (A.resum_every == 1 || (step > 0 && (A.resum_every > 1 ? step % (unsigned long long)A.resum_every == 0
-                                                                                 : (step % W == 0 && (step <= 10 * W || step % (10 * W) == 0)))));
+    // or (resum_every == 0, the default) never: the running sum is a compensated one (bb_opt_apply) and needs no re-adds -- each
+    // reads the whole window (32 D W bytes; C2 with W = 100: 0.8 GB, ~30 steps' worth of time)
+    w.resum = A.opt == 0 && (A.resum_every == 1 || (A.resum_every > 1 && step > 0 && step % (unsigned long long)A.resum_every == 0));
     return w;
 }
 
 // One optimiser update of parameter *p with gradient-of-(-ELBO) d.  which: 0 = mu, 1 = omega.
+// (*acc, *lo): the element's compensated running window sum.
+// a pair's four low-order parts: [mu 0, omega 0, mu 1, omega 1]
+struct bb_f4 { float x, y, z, w; };
+BB_DEV bb_f4 bb_load_lo(const DevState& S, long long i0, bool a0, bool a1) {
+    bb_f4 v{0.f, 0.f, 0.f, 0.f};
+    if (a0) { v.x = S.accl[2 * i0]; v.y = S.accl[2 * i0 + 1]; }
+    if (a1) { v.z = S.accl[2 * i0 + 2]; v.w = S.accl[2 * i0 + 3]; }
+    return v;
+}
+BB_DEV void bb_store_lo(const DevState& S, long long i0, bool a0, bool a1, const bb_f4& v) {
+    if (a0) { S.accl[2 * i0] = v.x; S.accl[2 * i0 + 1] = v.y; }
+    if (a1) { S.accl[2 * i0 + 2] = v.z; S.accl[2 * i0 + 3] = v.w; }
+}
+// error-free sum: a + b = s + e exactly
+BB_DEV void bb_two_sum(double a, double b, double* s, double* e) {
+    const double t = a + b, bb = t - a;
+    *s = t;
+    *e = (a - (t - bb)) + (b - bb);
+}
 BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot w,
-                         int which, long long i, double d, double old_slot, double* new_slot, double* p, double* acc) {
+                         int which, long long i, double d, double old_slot, double* new_slot, double* p, double* acc, float* lo) {
     double upd;
     if (A.opt == 0) {   // TruncatedADAGrad: g2[mod(i-1,n)+1] = d^2; s = sum(g2); d *= eta / (tau + sqrt(s))
         const double n2 = d * d;
         *new_slot = n2;
-        // running sum acc + d^2 - (slot leaving the window); where that difference has cancelled more than 24 bits (a gradient
-        // spike leaving the window: t >> s, or a negative rounding residue) this ELEMENT's window is re-added exactly on the
-        // spot, whatever the schedule says -- rare, and it bounds the running sum's relative error by 2^-29 between re-adds
-        const double t = *acc + n2;
-        double s = t - old_slot;
-        if (w.resum || t > BB_GUARD * s) {
+        // Running sum acc + d^2 - (slot leaving the window).  A plain double leaves up to half an ulp of the CURRENT sum behind at
+        // every step, and that residue stays while the sum itself falls by orders of magnitude (the first gradients are ~1e6
+        // times the later ones): measured on C2, 1500 steps, 0.2 in mu against the exact window with re-adds every ten windows,
+        // 5e-5 with one per window early on.  (A per-element "re-add when the sum has fallen 2^16 below its largest value"
+        // guard fixes the accuracy -- 8e-9 -- but some wave of the grid trips it at almost every step and the whole lock-stepped
+        // grid waits for its 100-slot re-add: 15.3 -> 19.8 us per step.)  So the sum is kept as an unevaluated pair (acc, lo):
+        // both updates go through an error-free two-sum, the rounding errors collect in lo (a float: 53 + 24 bits together, the
+        // sum may fall 2^24 below its peak and still be exact to the last bit of a double).  No re-adds, no divergence, no
+        // window traffic beyond the one slot.
+        double s;
+        if (w.resum) {
             s = 0.0;
             for (int j = 0; j < A.W; ++j) s += (j == w.slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
+            *lo = 0.f;
+        } else {
+            double t, e1, u, e2;
+            bb_two_sum(*acc, n2, &t, &e1);
+            bb_two_sum(t, -old_slot, &u, &e2);
+            const double l = (double)*lo + (e1 + e2);
+            s = u + l;
+            *lo = (float)(l - (s - u));
+            s = s > 0.0 ? s : 0.0;            // (an all-zero window can come out as -1e-60)
         }
         *acc = s;
         upd = d * (A.eta * bb_rcp(A.tau + bb_sqrt(s)));
@@ -429,14 +457,16 @@ BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& 
         hm = a0 ? bb_d2{hm_, 0} : bb_d2{0, hm_}; ho = a0 ? bb_d2{ho_, 0} : bb_d2{0, ho_};
     }
     bb_d2 nhm = hm, nho = ho;
+    bb_f4 lo = bb_load_lo(S, i0, a0, a1);
     if (a0) {
-        bb_opt_apply(M, S, A, w, 0, i0, -gm[0], hm.x, &nhm.x, &mu.x, &am.x);
-        bb_opt_apply(M, S, A, w, 1, i0, -go[0], ho.x, &nho.x, &om.x, &ao.x);
+        bb_opt_apply(M, S, A, w, 0, i0, -gm[0], hm.x, &nhm.x, &mu.x, &am.x, &lo.x);
+        bb_opt_apply(M, S, A, w, 1, i0, -go[0], ho.x, &nho.x, &om.x, &ao.x, &lo.y);
     }
     if (a1) {
-        bb_opt_apply(M, S, A, w, 0, i1, -gm[1], hm.y, &nhm.y, &mu.y, &am.y);
-        bb_opt_apply(M, S, A, w, 1, i1, -go[1], ho.y, &nho.y, &om.y, &ao.y);
+        bb_opt_apply(M, S, A, w, 0, i1, -gm[1], hm.y, &nhm.y, &mu.y, &am.y, &lo.z);
+        bb_opt_apply(M, S, A, w, 1, i1, -go[1], ho.y, &nho.y, &om.y, &ao.y, &lo.w);
     }
+    bb_store_lo(S, i0, a0, a1, lo);
     if (both) {
         *(bb_d2*)(S.mu + i0) = mu; *(bb_d2*)(S.om + i0) = om;
         *(bb_d2*)(S.acc_mu + i0) = am; *(bb_d2*)(S.acc_om + i0) = ao;
@@ -1049,17 +1079,24 @@ BB_DEV void bb_block_geno(BBCtx& cx, const DevModel& M, const DevState& S, const
     }
 }
 
-// theta rows of the genotype model (mu, omega, the two accumulators, 2 W window rows) <-> a packed buffer [rows][G]; packing
+// theta rows of the genotype model (mu, omega, the two accumulators and their low-order parts, 2 W window rows) <-> a packed buffer [rows][G]; packing
 // writes zeros for the genotypes outside [g_lo, g_hi), so that the sum over all shards' buffers is the gather from the owners.
 BB_DEV void bb_block_theta_pack(BBCtx& cx, const DevModel& M, const DevState& S, double* buf, int g_lo, int g_hi, int W, int unpack, int nblocks) {
-    const long long total = (long long)(4 + 2 * W) * M.G;
+    const long long total = (long long)(6 + 2 * W) * M.G;
     BB_PASS(cx, tid) {
         for (long long i = (long long)cx.block * cx.nthr + tid; i < total; i += (long long)nblocks * cx.nthr) {
             const int a = (int)(i / M.G), g = (int)(i - (long long)a * M.G);
-            double* p = a == 0 ? S.mu : (a == 1 ? S.om : (a == 2 ? S.acc_mu : (a == 3 ? S.acc_om : S.hist + (long long)(a - 4) * M.Dp)));
+            const bool own = g >= g_lo && g < g_hi;
+            if (a == 4 || a == 5) {          // the accumulators' low-order parts (floats)
+                float* q = S.accl + 2 * (M.blk_lo[BK_S] + g) + (a - 4);
+                if (unpack) *q = (float)buf[i];
+                else buf[i] = own ? (double)*q : 0.0;
+                continue;
+            }
+            double* p = a == 0 ? S.mu : (a == 1 ? S.om : (a == 2 ? S.acc_mu : (a == 3 ? S.acc_om : S.hist + (long long)(a - 6) * M.Dp)));
             p += M.blk_lo[BK_S] + g;
             if (unpack) *p = buf[i];
-            else buf[i] = (g >= g_lo && g < g_hi) ? *p : 0.0;
+            else buf[i] = own ? *p : 0.0;
         }
     }
 }

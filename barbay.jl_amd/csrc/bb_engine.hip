@@ -1122,6 +1122,7 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &S.hsv, D + 2));
     BB_TRY(dalloc(h, &S.acc_mu, D + 2));
     BB_TRY(dalloc(h, &S.acc_om, D + 2));
+    BB_TRY(dalloc(h, &S.accl, 2 * D + 8));
     BB_TRY(dalloc(h, &S.gacc_mu, D + 2));
     BB_TRY(dalloc(h, &S.gacc_om, D + 2));
     BB_TRY(dalloc(h, &h->bak_mu, D + 2));
@@ -1338,7 +1339,7 @@ static int allreduce(bb_handle* h, double* buf, size_t n) {
 
 // Genotype model with the shards cut at genotype boundaries: a resident run updates theta_g on its owner only.  Gathering the
 // owners' copies (parameters, optimiser accumulators, window rows) = summing rows that hold zeros for what a shard does not own.
-static size_t theta_rows(const bb_handle* h) { return 4 + (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD ? 2 * (size_t)h->o.window : 0); }
+static size_t theta_rows(const bb_handle* h) { return 6 + (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD ? 2 * (size_t)h->o.window : 0); }
 static bool theta_partial(const bb_handle* h) { return h->M.kind == BB_MODEL_GENOTYPE && (h->g_lo > 0 || h->g_hi < h->M.G); }
 static int theta_pack(bb_handle* h, int unpack) {
     const size_t n = theta_rows(h) * (size_t)h->M.G;
@@ -1427,6 +1428,7 @@ static int set_step(bb_handle* h, long long step) {
 static int reset_optimizer(bb_handle* h) {
     const size_t D = (size_t)h->M.D;
     int rc;
+    if ((rc = dzero(h->S.accl, (2 * D + 8) * 4, h->stream))) return rc;
     if (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD) {
         if ((rc = dzero(h->S.hist, (size_t)h->o.window * 2 * (size_t)h->M.Dp * 8, h->stream))) return rc;
         if ((rc = dzero(h->S.acc_mu, D * 8, h->stream))) return rc;

@@ -35,6 +35,7 @@ struct BBPst {
     bb_d2 hm[P], ho[P];                 // this step's TruncatedADAGrad window slot, fetched while the exchange is in flight
     long long i0[P];                    // first latent of each pair
     int meta[P];                        // segment index | a0 << 8 | a1 << 9 | valid << 10
+    bb_f4 lo[P];                        // low-order parts of the four running window sums (bb_opt_apply)
 };
 
 #ifdef BB_EMU
@@ -125,6 +126,7 @@ BB_DEV void bbp_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const 
             st.om[k] = bb_load_pair(S.om, q.i0, q.a0, q.a1);
             st.am[k] = bb_load_pair(S.acc_mu, q.i0, q.a0, q.a1);
             st.ao[k] = bb_load_pair(S.acc_om, q.i0, q.a0, q.a1);
+            st.lo[k] = bb_load_lo(S, q.i0, q.a0, q.a1);
             st.a[k] = st.h[k] = st.hm[k] = st.ho[k] = bb_d2{0.0, 0.0};
             bb_u2 c{0u, 0u};
             if (q.valid && q.s.kind == SK_L) {
@@ -577,12 +579,12 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             const bb_d2 hm = hs_m ? st.hm[k] : bb_d2{0, 0}, ho = hs_m ? st.ho[k] : bb_d2{0, 0};
             bb_d2 nhm = hm, nho = ho;
             if (q.a0) {
-                bb_opt_apply(M, S, A, wslot, 0, q.i0, -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x);
-                bb_opt_apply(M, S, A, wslot, 1, q.i0, -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x);
+                bb_opt_apply(M, S, A, wslot, 0, q.i0, -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x, &st.lo[k].x);
+                bb_opt_apply(M, S, A, wslot, 1, q.i0, -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x, &st.lo[k].y);
             }
             if (q.a1) {
-                bb_opt_apply(M, S, A, wslot, 0, q.i0 + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y);
-                bb_opt_apply(M, S, A, wslot, 1, q.i0 + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y);
+                bb_opt_apply(M, S, A, wslot, 0, q.i0 + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y, &st.lo[k].z);
+                bb_opt_apply(M, S, A, wslot, 1, q.i0 + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
             }
             if (k == 0) BB_STAMP_W(cx, S, 31);
             if (hs_m) { bb_store_pair(hs_m, q.i0, q.a0, q.a1, nhm); bb_store_pair(hs_o, q.i0, q.a0, q.a1, nho); }
@@ -612,6 +614,7 @@ BB_DEV void bbp_epilogue(BBCtx& cx, const DevModel& M, const DevState& S, const 
             bb_store_pair(S.om, q.i0, q.a0, q.a1, st.om[k]);
             bb_store_pair(S.acc_mu, q.i0, q.a0, q.a1, st.am[k]);
             bb_store_pair(S.acc_om, q.i0, q.a0, q.a1, st.ao[k]);
+            bb_store_lo(S, q.i0, q.a0, q.a1, st.lo[k]);
             const double chk = (q.a0 ? st.mu[k].x + st.om[k].x : 0.0) + (q.a1 ? st.mu[k].y + st.om[k].y : 0.0);
             bad = bad || !(chk - chk == 0.0);        // NaN or +-Inf anywhere in the pair's variational parameters
         }

@@ -174,6 +174,7 @@ struct BRSt {
                                         // hierarchical unit pairs and loglambda pairs: see thoff
     int thoff[P];                       // hierarchical models: stage index of a unit minus thoff = index of its theta (r NB E_)
     unsigned cnt[P][2];                 // loglambda: the two counts
+    bb_f4 lo[P];                        // low-order parts of the four running window sums (bb_opt_apply)
 };
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
@@ -379,6 +380,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.om[k] = bb_load_pair(S.om, i0, a0, a1);
             st.am[k] = bb_load_pair(S.acc_mu, i0, a0, a1);
             st.ao[k] = bb_load_pair(S.acc_om, i0, a0, a1);
+            st.lo[k] = bb_load_lo(S, i0, a0, a1);
             st.a[k] = st.h[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
         }
     }
@@ -819,15 +821,15 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             }
             bb_d2 nhm = hm, nho = ho;
             if (a0) {
-                bb_opt_apply(M, S, A, wslot, 0, st.i0[k], -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x);
+                bb_opt_apply(M, S, A, wslot, 0, st.i0[k], -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x, &st.lo[k].x);
                 BR_SCHED_FENCE();
-                bb_opt_apply(M, S, A, wslot, 1, st.i0[k], -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x);
+                bb_opt_apply(M, S, A, wslot, 1, st.i0[k], -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x, &st.lo[k].y);
                 BR_SCHED_FENCE();
             }
             if (a1) {
-                bb_opt_apply(M, S, A, wslot, 0, st.i0[k] + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y);
+                bb_opt_apply(M, S, A, wslot, 0, st.i0[k] + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y, &st.lo[k].z);
                 BR_SCHED_FENCE();
-                bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y);
+                bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
                 BR_SCHED_FENCE();
             }
             if (hs_m) { bb_store_pair(hs_m, st.i0[k], a0, a1, nhm); bb_store_pair(hs_o, st.i0[k], a0, a1, nho); }
@@ -853,6 +855,7 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
             bb_store_pair(S.om, st.i0[k], a0, a1, st.om[k]);
             bb_store_pair(S.acc_mu, st.i0[k], a0, a1, st.am[k]);
             bb_store_pair(S.acc_om, st.i0[k], a0, a1, st.ao[k]);
+            bb_store_lo(S, st.i0[k], a0, a1, st.lo[k]);
             const double chk = (a0 ? st.mu[k].x + st.om[k].x : 0.0) + (a1 ? st.mu[k].y + st.om[k].y : 0.0);
             bad = bad || !(chk - chk == 0.0);
         }

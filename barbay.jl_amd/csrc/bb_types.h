@@ -58,6 +58,8 @@ struct DevState {
     double *zsv, *asv, *hsv;          // [D] per-sample scratch: z, eps*sigmoid(omega) (= dz/domega), sigmoid/softplus (= dH/domega)
     double *acc_mu, *acc_om;          // [D] optimiser accumulators
     double *hist;                     // [W][2][Dp] TruncatedADAGrad window of squared gradients
+    float *accl;                      // [2 D] low-order parts of the running window sums: (acc_mu[i], accl[2 i]) and (acc_om[i], accl[2 i + 1]) are
+                                      // compensated (two-sum) accumulators, bb_opt_apply
     double *gacc_mu, *gacc_om;        // [D] S > 1 accumulation / gradient export
     double *partials;                 // [2][K][nblk] (second half: odd steps of the persistent launch)
     double *totals;                   // [K]

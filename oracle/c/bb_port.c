@@ -252,6 +252,12 @@ void port_normals(uint64_t seed, uint32_t step, uint32_t stream, int64_t D, doub
  *        reference's `sum(g2)`), else a running sum re-added exactly once per window for ten windows, then once per ten.
  * opt 1: DecayedADAGrad(eta, pre, post).
  * state: caller-allocated, zero-initialised: opt 0 -> (window + 1) * 2D doubles, opt 1 -> 2D doubles set to 1e-8. */
+static void port_two_sum(double a, double b, double* s, double* e) {   /* a + b = s + e exactly */
+    const double t = a + b, bb = t - a;
+    *s = t;
+    *e = (a - (t - bb)) + (b - bb);
+}
+
 int port_run(const port_model* M, double* mu, double* omega, int64_t first_step, int64_t n_steps, int S, int opt,
              double eta, double tau, int window, int window_exact, double pre, double post, uint64_t seed,
              double* state, double* elbo_trace /* n_steps or NULL */, int nthreads) {
@@ -269,22 +275,35 @@ int port_run(const port_model* M, double* mu, double* omega, int64_t first_step,
         const double el = port_elbo_grad(M, mu, omega, eps, S, gmu, gom, work, nthreads);
         if (elbo_trace) elbo_trace[it - first_step] = el;
         const int slot = (int)(it % window);
-        /* default schedule of the engine (bb_slot_of): once per window during the first ten windows, then once per ten */
-        const int resum = window_exact || (it > 0 && it % window == 0 && (it <= 10 * (int64_t)window || it % (10 * (int64_t)window) == 0));
+        /* the engine's schedule (bb_slot_of): exact re-add every step (window_exact) or never -- the running sum is compensated */
+        const int resum = window_exact;
 #pragma omp parallel for schedule(static)
         for (int64_t j = 0; j < 2 * D; ++j) {
             double* p = j < D ? &mu[j] : &omega[j - D];
             const double d = -gmu[j];               /* gradient of -ELBO; gmu/gom are contiguous */
             double upd;
             if (opt == 0) {
-                double* hist = state;               /* [window][2D] */
+                double* hist = state;               /* [window][2D], then acc [2D], then their low-order parts [2D] */
                 double* acc = state + (int64_t)window * 2 * D;
+                double* lo = acc + 2 * D;             /* low-order parts (the engine keeps them as floats) */
                 const double n2 = d * d, old = hist[(int64_t)slot * 2 * D + j];
                 hist[(int64_t)slot * 2 * D + j] = n2;
-                /* running sum; an element whose difference cancelled more than 24 bits is re-added exactly (engine: bb_opt_apply) */
-                const double t = acc[j] + n2;
-                double sacc = t - old;
-                if (resum || t > 0x1p24 * sacc) { sacc = 0.0; for (int k = 0; k < window; ++k) sacc += hist[(int64_t)k * 2 * D + j]; }
+                /* compensated running sum (engine: bb_opt_apply, same arithmetic): two error-free sums, the rounding errors
+                   collect in a float */
+                double sacc;
+                if (resum) {
+                    sacc = 0.0;
+                    for (int k = 0; k < window; ++k) sacc += hist[(int64_t)k * 2 * D + j];
+                    lo[j] = 0.0;
+                } else {
+                    double t, e1, u, e2;
+                    port_two_sum(acc[j], n2, &t, &e1);
+                    port_two_sum(t, -old, &u, &e2);
+                    const double l = lo[j] + (e1 + e2);
+                    sacc = u + l;
+                    lo[j] = (double)(float)(l - (sacc - u));
+                    sacc = sacc > 0.0 ? sacc : 0.0;
+                }
                 acc[j] = sacc;
                 upd = d * (eta / (tau + sqrt(sacc)));
             } else {

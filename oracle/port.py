@@ -107,7 +107,7 @@ class Port:
         omega = np.array(omega, dtype=np.float64)
         opt = 0 if optimizer == "TruncatedADAGrad" else 1
         if state is None:
-            state = np.zeros((window + 1) * 2 * self.D) if opt == 0 else np.full(2 * self.D, 1e-8)
+            state = np.zeros((window + 2) * 2 * self.D) if opt == 0 else np.full(2 * self.D, 1e-8)   # window, running sums, their low-order parts
         trace = np.empty(n_steps)
         rc = lib().port_run(C.byref(self.m), _p(mu), _p(omega), first_step, n_steps, S, opt, eta, tau, window,
                             int(window_exact), pre, post, seed, _p(state), _p(trace), nthreads)

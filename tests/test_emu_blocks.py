@@ -152,6 +152,22 @@ def test_genotype_empty_genotypes_and_unsorted(emu_lib, monkeypatch):
         make_engine(c.synth("genotype"), emu_lib, launch_mode=2)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_running_window_stays_near_the_exact_window(emu_lib, mode):
+    """TruncatedADAGrad's window sum is kept as a running sum; the per-element guard of bb_opt_apply (largest exponent since
+    the last exact sum, one byte per parameter) re-adds an element's window once the sum has fallen far below it.  Against the
+    reference's arithmetic (the window added up every step): with the default schedule and with the guard alone."""
+    from conftest import make_engine
+    sp = c.synth("fitness_T6", seed=6)
+    outs = {}
+    for resum in (1, 0, 100000):
+        with make_engine(sp, emu_lib, seed=13, window=10, resum_every=resum, launch_mode=mode) as e:
+            e.run(300)
+            outs[resum] = e.get_params()
+    for resum in (0, 100000):
+        assert np.abs(outs[resum][0] - outs[1][0]).max() < 1e-9 and np.abs(outs[resum][1] - outs[1][1]).max() < 1e-9
+
+
 def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NB", "120")     # 120 barcodes x (16 + 1 + 9) latents / 2 > 1024 pairs -> P = 2
     monkeypatch.setenv("BB_TUNE_NTHR", "1024")
