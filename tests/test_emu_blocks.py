@@ -154,9 +154,9 @@ def test_genotype_empty_genotypes_and_unsorted(emu_lib, monkeypatch):
 
 @pytest.mark.parametrize("mode", [1, 2])
 def test_running_window_stays_near_the_exact_window(emu_lib, mode):
-    """TruncatedADAGrad's window sum is kept as a running sum; the per-element guard of bb_opt_apply (largest exponent since
-    the last exact sum, one byte per parameter) re-adds an element's window once the sum has fallen far below it.  Against the
-    reference's arithmetic (the window added up every step): with the default schedule and with the guard alone."""
+    """TruncatedADAGrad's window sum is kept as a compensated running sum (bb_opt_apply: two error-free sums per step, the
+    rounding errors in a float beside the accumulator) and never re-added.  Against the reference's arithmetic (the window added
+    up every step): the default, and a re-add period that never comes."""
     from conftest import make_engine
     sp = c.synth("fitness_T6", seed=6)
     outs = {}
