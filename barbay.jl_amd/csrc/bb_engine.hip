@@ -497,7 +497,7 @@ static bool build_geno_tiles(const bb_handle* h, int NB, int NBL, std::vector<lo
     tg.clear();
     long long b = h->b_lo;
     while (b < h->b_hi) {
-        const int cap = (NBL > 0 && tb.size() < 8) ? NBL : NB;
+        const int cap = (NBL > 0 && tb.size() < (size_t)BB_NG) ? NBL : NB;
         long long e = std::min<long long>(b + cap, h->b_hi);
         if (e < h->b_hi && e > M.nn) {
             e = M.nn + ptr[(size_t)geno_of(e - M.nn)];       // back to the first mutant of the genotype the cut fell into
@@ -527,12 +527,12 @@ static bool try_resident(bb_handle* h) {
     const bool nb_fixed = getenv("BB_TUNE_NB") != nullptr;
     if (pct < 100 && h->nblk >= 16 && (!nb_fixed || ev)) {
         if (!nb_fixed) {
-            const double tiles = (double)h->nblk - 8.0 * (1.0 - pct / 100.0);      // in units of a full tile
+            const double tiles = (double)h->nblk - (double)BB_NG * (1.0 - pct / 100.0);      // in units of a full tile
             NB = (int)std::ceil((double)nbar / tiles);
         }
         NBL = std::max(1, (int)(NB * (pct / 100.0)));
-        const long long rest = nbar - 8ll * NBL;
-        nblk = 8 + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
+        const long long rest = nbar - (long long)BB_NG * NBL;
+        nblk = BB_NG + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
         const long long p_uni = (br_tile_span(h->M, h->NB, true) + h->nthr - 1) / h->nthr, p_new = (br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr;
         // stay uniform where rounding pushed the map over the grid that fits, or the slightly larger tiles need another pair slot
         if (nblk > h->nblk + (nb_fixed ? 8 : 0) || p_new > p_uni) { NB = h->NB; NBL = 0; nblk = h->nblk; }
@@ -1150,8 +1150,8 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     }
 #endif
     BB_TRY(dalloc(h, &S.prow, (size_t)(h->nblk + 8) * (M.K + 2 * M.nt1)));      // (+ 8: k_res's own tile map may need a few tiles more)
-    BB_TRY(dalloc(h, &S.xrow, (size_t)2 * 8 * (M.K + 2 * M.nt1)));
-    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 16)));
+    BB_TRY(dalloc(h, &S.xrow, (size_t)2 * BB_NG * (M.K + 2 * M.nt1)));
+    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 2 * BB_NG)));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));

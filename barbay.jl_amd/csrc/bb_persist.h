@@ -310,7 +310,10 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
 // row of the previous step, which the leaders publish only after reading all member rows).  Every poll is bounded.
 typedef unsigned long long bb_u64;
 
-BB_DEV int bbp_groups(int nblk) { return nblk < 8 ? nblk : 8; }
+#ifndef BB_NG
+#define BB_NG 8            /* groups of the exchange's first hop on one GPU (the cross-GPU inbox protocol is laid out for 8) */
+#endif
+BB_DEV int bbp_groups(int nblk) { return nblk < BB_NG ? nblk : BB_NG; }
 
 // Poll *word until it equals epoch; false = gave up (timeout word set).
 BB_DEV bool bb_wait_word(const unsigned* word, unsigned epoch, unsigned* tmo, unsigned limit) {
@@ -507,12 +510,12 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
     BB_STAMP(cx, S, 1);
     BB_PASS(cx, tid) {
         for (int k = tid; k < KK; k += cx.nthr) {
-            double v[8];
+            double v[BB_NG];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) v[g] = g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g) * KK + k) : 0.0;
+            for (int g = 0; g < BB_NG; ++g) v[g] = g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g) * KK + k) : 0.0;
             double s = 0.0;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += v[g];
+            for (int g = 0; g < BB_NG; ++g) s += v[g];
             if (k < M.K) bb_put_total(M, L, lds, k, s);
             else lds[L.zgl + (k - M.K)] = s;
         }

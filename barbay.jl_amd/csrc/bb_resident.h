@@ -184,7 +184,7 @@ enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, B
 // rows arrive, and the group rows appear one draw (~5 k cycles) sooner for all tiles.
 BB_DEV BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
     if (A.nbl <= 0) return bb_tile(M, A, block, NB);
-    const int nlead = A.nblk < 8 ? A.nblk : 8;
+    const int nlead = A.nblk < BB_NG ? A.nblk : BB_NG;
     BBTile t;
     t.NB = NB;
     const int cap = block < nlead ? A.nbl : NB;
