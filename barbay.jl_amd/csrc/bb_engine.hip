@@ -704,11 +704,11 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
         BRSt<PP>* sb = st + (size_t)b * h->nthr;
         if (phase == 0) {
             br_prologue<KIND, PP>(cx, h->M, h->S, A, Y, h->res_NB, sb);
-            br_draw_ahead<PP>(cx, A, Y, sb, (unsigned long long)h->step);
+            br_draw_ahead<KIND, PP>(cx, A, Y, sb, (unsigned long long)h->step);
         } else if (phase == 1) {
             br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
             br_moments<KIND, PP>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<PP>(cx, h->M, h->S, A, Y, sb, step);
+            br_xchg_publish<KIND, PP>(cx, h->M, h->S, A, Y, sb, step);
         } else if (phase == 2) {
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);
             else br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
@@ -720,7 +720,7 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             else if (uniform_T(h->M) == 6) br_update<KIND, PP, 6>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
             else br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
         } else {
-            br_epilogue<PP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
+            br_epilogue<KIND, PP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
     }
 }

@@ -23,9 +23,10 @@
 //
 // Lane mapping: every loglambda segment (one per replicate) starts at a wave boundary; LPB = T/2 lanes per barcode,
 // lane = bl * LPB + k owns (b, 2k), (b, 2k+1).  Their moment contributions go to LDS transposed (one column entry per lane)
-// and are summed by column walks of stride LPB.  Unit pairs follow, flat.  Needs: every T_r even and <= 16, the loglambda
-// block starting at an even flat index (pairs then never straddle barcodes), not the ragged-method quirk; other shapes keep
-// k_persist.
+// and are summed by column walks of stride LPB.  Unit pairs follow, flat.  Needs: every T_r even and <= 16 (a barcode's time
+// points then split into whole pairs), not the ragged-method quirk; other shapes keep k_persist.  A loglambda pair is (b, 2k),
+// (b, 2k+1); where the block starts at an odd flat index (genotype model only, br_eligible) the two latents belong to two
+// different Philox pairs (two draws) and move as 8-byte accesses.
 //
 // Written, like bb_persist.h, as passes over an explicit per-thread state so that the host emulation (tests) runs the
 // same source; the wave-level operations (a DPP row sum, the LDS-DMA prefetch) have emulation twins that add / move the same
@@ -92,8 +93,10 @@ static inline bool br_eligible(const DevModel& M) {
     if (M.kind == 2 && !M.geno_sorted) return false;   // (genotype model: tiles must own whole genotypes, see br_tile_geno)
     if (M.quirk || M.Ttot > 64) return false;
     for (int r = 0; r < M.R; ++r) if ((M.T[r] & 1) || M.T[r] > BR_MAXT) return false;
-    if (M.blk_lo[BK_L] & 1) return false;
-    for (int r = 0; r < M.R; ++r) if (M.off_l[r] & 1) return false;
+    // loglambda at an odd flat index (pairs (b, 2k), (b, 2k+1) then straddle two Philox pairs): built for the genotype model only,
+    // whose other choice is the two-kernel step; the replicate models keep k_persist there (the run-time choice cost C3's
+    // instance 3 %).  Fitness / multienv layouts always start it at an even index.
+    if (M.kind != 2 && ((M.blk_lo[BK_L] & 1) || (M.off_l[0] & 1))) return false;
     return true;
 }
 
@@ -178,6 +181,20 @@ struct BRSt {
 };
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
+
+// Pair accesses.  In the fitness / multienv layouts an even number of latents precedes the loglambda block (two blocks of T - 1,
+// two of n_bc E), so a pair always sits at an even flat index; in the genotype layout (theta: n_geno, then 3 n_bc) it may sit at
+// an odd one -- then two 8-byte accesses, and two Philox pairs' halves for its normals (br_draw_call).
+template <int KIND> BB_DEV bool br_pair_aligned(long long i0) { return KIND != 2 || !(i0 & 1); }
+template <int KIND> BB_DEV bb_d2 br_load_pair(const double* base, long long i0, bool a0, bool a1) {
+    if (a0 && a1 && br_pair_aligned<KIND>(i0)) return *(const bb_d2*)(base + i0);
+    return bb_d2{a0 ? base[i0] : 0.0, a1 ? base[i0 + 1] : 0.0};
+}
+template <int KIND> BB_DEV void br_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v) {
+    if (a0 && a1 && br_pair_aligned<KIND>(i0)) { *(bb_d2*)(base + i0) = v; return; }
+    if (a0) base[i0] = v.x;
+    if (a1) base[i0 + 1] = v.y;
+}
 
 // Tile map of k_res.  The group leaders of the exchange (tiles 0 .. 7) do extra work between their publish and everybody's
 // consume; with nbl < NB barcodes they reach their publish early enough to have drawn their next normals before their members'
@@ -376,10 +393,10 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.i0[k] = i0;
             st.meta[k] = meta;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            st.mu[k] = bb_load_pair(S.mu, i0, a0, a1);
-            st.om[k] = bb_load_pair(S.om, i0, a0, a1);
-            st.am[k] = bb_load_pair(S.acc_mu, i0, a0, a1);
-            st.ao[k] = bb_load_pair(S.acc_om, i0, a0, a1);
+            st.mu[k] = br_load_pair<KIND>(S.mu, i0, a0, a1);
+            st.om[k] = br_load_pair<KIND>(S.om, i0, a0, a1);
+            st.am[k] = br_load_pair<KIND>(S.acc_mu, i0, a0, a1);
+            st.ao[k] = br_load_pair<KIND>(S.acc_om, i0, a0, a1);
             st.lo[k] = bb_load_lo(S, i0, a0, a1);
             st.a[k] = st.h[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
         }
@@ -390,7 +407,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
 // ---- next step's standard normals (out of line on the GPU, as in bb_persist.h) -----------------------------------
 template <int P> struct BRIdx { long long i0[P]; int meta[P]; };
 
-template <int P>
+template <int P, bool MAYODD>
 #ifdef BB_EMU
 static inline
 #else
@@ -400,13 +417,24 @@ void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsign
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         if (!(ix.meta[k] & BRM_VALID)) continue;
-        double e0, e1;
-        bb_normal_pair(seed, (unsigned long long)(ix.i0[k] >> 1), step, 0u, &e0, &e1);
+        // Where the loglambda block starts at an odd flat index (an odd number of latents in front of it) the thread's two
+        // latents are the SECOND of one Philox pair and the FIRST of the next: two draws, in the exchange's shadow like the one.
+        // One call site run once or twice (a second inlined copy enlarged the function's register footprint, which the step
+        // loop pays for around the call: C3's instance 60 -> 96 spilled registers).
+        const bool odd = MAYODD && (ix.i0[k] & 1);
+        double e0 = 0.0, e1 = 0.0;
+#pragma nounroll
+        for (int rep = 0; rep < (odd ? 2 : 1); ++rep) {
+            double a, b;
+            bb_normal_pair(seed, (unsigned long long)(ix.i0[k] >> 1) + (unsigned long long)rep, step, 0u, &a, &b);
+            if (rep == 0) { e0 = odd ? b : a; e1 = b; }
+            else e1 = a;
+        }
         eps[k * nthr + tid] = bb_d2{e0, e1};              // read back by the same thread: no barrier needed
     }
 }
 
-template <int P>
+template <int KIND, int P>
 BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
     bb_d2* eps = (bb_d2*)(cx.lds + Y.eps);
     BB_PASS(cx, tid) {
@@ -414,7 +442,7 @@ BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* 
         BRIdx<P> ix;
 #pragma unroll
         for (int k = 0; k < P; ++k) { ix.i0[k] = st.i0[k]; ix.meta[k] = st.meta[k]; }
-        br_draw_call<P>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
+        br_draw_call<P, (KIND == 2)>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
     }
 }
 
@@ -832,7 +860,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
                 BR_SCHED_FENCE();
             }
-            if (hs_m) { bb_store_pair(hs_m, st.i0[k], a0, a1, nhm); bb_store_pair(hs_o, st.i0[k], a0, a1, nho); }
+            if (hs_m) { br_store_pair<KIND>(hs_m, st.i0[k], a0, a1, nhm); br_store_pair<KIND>(hs_o, st.i0[k], a0, a1, nho); }
         }
     }
     }
@@ -841,7 +869,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
 }
 
 // ---- epilogue: state back to memory, step counter, status words ----------------------------------------------------------
-template <int P>
+template <int KIND, int P>
 BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned long long step_end, bool timed_out) {
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
@@ -851,10 +879,10 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
             const int meta = st.meta[k];
             if (!(meta & BRM_VALID)) continue;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            bb_store_pair(S.mu, st.i0[k], a0, a1, st.mu[k]);
-            bb_store_pair(S.om, st.i0[k], a0, a1, st.om[k]);
-            bb_store_pair(S.acc_mu, st.i0[k], a0, a1, st.am[k]);
-            bb_store_pair(S.acc_om, st.i0[k], a0, a1, st.ao[k]);
+            br_store_pair<KIND>(S.mu, st.i0[k], a0, a1, st.mu[k]);
+            br_store_pair<KIND>(S.om, st.i0[k], a0, a1, st.om[k]);
+            br_store_pair<KIND>(S.acc_mu, st.i0[k], a0, a1, st.am[k]);
+            br_store_pair<KIND>(S.acc_om, st.i0[k], a0, a1, st.ao[k]);
             bb_store_lo(S, st.i0[k], a0, a1, st.lo[k]);
             const double chk = (a0 ? st.mu[k].x + st.om[k].x : 0.0) + (a1 ? st.mu[k].y + st.om[k].y : 0.0);
             bad = bad || !(chk - chk == 0.0);
@@ -867,12 +895,12 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 }
 
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
-template <int P>
+template <int KIND, int P>
 BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
     // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
     br_prefetch_slot<P>(cx, M, S, A, Y, stv, step);
-    br_draw_ahead<P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
+    br_draw_ahead<KIND, P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
 }
 template <bool XG>
 BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, unsigned long long step, int* ok_slot) {
@@ -908,14 +936,14 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
     const bool dead = *ok_slot == 0;
     int done = 0;
     if (!dead) {
-        br_draw_ahead<P>(cx, A, Y, &st, step0);
+        br_draw_ahead<KIND, P>(cx, A, Y, &st, step0);
         BB_STAMP_RT(cx, S, 4);
         for (; done < nsteps; ++done) {
             const unsigned long long step = step0 + (unsigned long long)done;
             const int buf = (int)(step & 1);
             br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
             br_moments<KIND, P>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<P>(cx, M, S, A, Y, &st, step);
+            br_xchg_publish<KIND, P>(cx, M, S, A, Y, &st, step);
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
             if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
@@ -923,7 +951,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
         }
     }
     BB_STAMP_RT(cx, S, 5);
-    br_epilogue<P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
+    br_epilogue<KIND, P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
     BB_STAMP_RT(cx, S, 6);
 }
 #endif

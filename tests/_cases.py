@@ -28,7 +28,9 @@ SYNTH = {
     "multienv": ("multienv", dict(B=600, T=7, n_env=3, n_neutral=11)),
     "genotype": ("genotype", dict(B=800, T=6, n_geno=17, n_neutral=256)),
     "genotype_runs": ("genotype", dict(B=800, T=6, n_geno=40, n_neutral=256, geno_runs=True)),   # mutants grouped by genotype: k_res owns whole genotypes per tile
-    "genotype_T8": ("genotype", dict(B=1000, T=8, n_geno=60, n_neutral=30, geno_runs=True)),      # (an even number of genotypes: loglambda then starts at an even flat index)
+    "genotype_T8": ("genotype", dict(B=1000, T=8, n_geno=60, n_neutral=30, geno_runs=True)),
+    "genotype_odd": ("genotype", dict(B=800, T=6, n_geno=41, n_neutral=256, geno_runs=True)),      # loglambda starts at an ODD flat index: a k_res pair is two Philox pairs' halves
+    "replicate_odd": ("replicate", dict(B=302, T=[6, 4], n_rep=2, n_neutral=1)),                  # ... likewise (301 mutants, two replicates): k_persist
     "replicate_ragged": ("replicate", dict(B=530, T=[5, 7, 4], n_rep=3, n_neutral=20)),
     "replicate_3d": ("replicate", dict(B=300, T=6, n_rep=2, n_neutral=1)),
     "multienv_replicate": ("multienv_replicate", dict(B=420, T=[5, 7, 4], n_rep=3, n_env=3, n_neutral=23)),

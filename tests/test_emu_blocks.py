@@ -109,6 +109,20 @@ def test_owner_computes_launch_genotype(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name", ["genotype_odd"])
+def test_owner_computes_launch_odd_loglambda_offset(emu_lib, monkeypatch, name):
+    """An odd number of latents in front of the loglambda block: a pair (b, 2k), (b, 2k+1) then straddles two Philox pairs
+    (2q - 1, 2q) -- two draws per thread, 8-byte state accesses; same draws, same arithmetic as everywhere else.  Also sharded.
+    (Built for the genotype model, whose other choice is the two-kernel step; replicate shapes like this keep k_persist.)"""
+    sp = c.synth(name, seed=6)
+    assert sp.offsets()["loglambda"][0] % 2 == 1
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
+    monkeypatch.setenv("BB_TUNE_NB", "24" if name == "genotype_odd" else "16")      # (>= 8 tiles per rank)
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
+    c.case_p2p_resident(emu_lib, name, 2)
+
+
 @pytest.mark.parametrize("nb,nthr,lead", [(24, 128, 100), (40, 256, 65), (64, 512, 50), (100, 1024, 100), (30, 64, 100)])
 def test_owner_computes_launch_genotype_geometries(emu_lib, monkeypatch, nb, nthr, lead):
     """several pair slots per thread, theta pairs split between two tiles, smaller leader tiles, the neutral / mutant boundary

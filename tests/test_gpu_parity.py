@@ -225,6 +225,16 @@ def test_owner_computes_launch_genotype(hip_lib, name):
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name", ["genotype_odd"])
+def test_owner_computes_launch_odd_loglambda_offset(hip_lib, monkeypatch, name):
+    """loglambda starting at an odd flat index: a k_res pair takes its normals from two Philox pairs and moves as 8-byte
+    accesses (the LDS-DMA window-slot prefetch from an 8-byte-aligned address)."""
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
+    monkeypatch.setenv("BB_TUNE_NB", "24" if name == "genotype_odd" else "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
+
+
 @pytest.mark.parametrize("nb,nthr,lead", [(24, 128, 100), (40, 256, 65), (64, 512, 50), (100, 1024, 100)])
 def test_owner_computes_launch_genotype_geometries(hip_lib, monkeypatch, nb, nthr, lead):
     monkeypatch.setenv("BB_TUNE_NB", str(nb))
@@ -234,11 +244,11 @@ def test_owner_computes_launch_genotype_geometries(hip_lib, monkeypatch, nb, nth
     c.case_persistent_equals_two_kernel(hip_lib, "genotype_T8", expect_kernel=2)
 
 
-@pytest.mark.parametrize("B,G", [(25_000, 626), (50_000, 1_250)])
+@pytest.mark.parametrize("B,G", [(25_000, 625), (50_000, 1_250)])
 def test_genotype_resident_at_shard_size(hip_lib, B, G):
-    """BASELINE config 5 as one rank of its 8-GPU run sees it (200 000 / 8 barcodes, 5 000 / 8 genotypes -- one genotype more:
-    a standalone problem needs an even count for loglambda to start at an even index), and about the largest genotype problem
-    whose state fits one GPU's registers: the resident launch against the two-kernel step."""
+    """BASELINE config 5 as one rank of its 8-GPU run sees it (200 000 / 8 barcodes, 5 000 / 8 genotypes; as a standalone
+    problem its loglambda block starts at an odd flat index), and about the largest genotype problem whose state fits one
+    GPU's registers: the resident launch against the two-kernel step."""
     from conftest import make_engine
     from barbay_jl_amd import synth
     from oracle import port

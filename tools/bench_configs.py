@@ -17,8 +17,8 @@ CFG = {
     "C3 replicate_fitness_normal 20000x6x3": lambda: synth.replicate_fitness_normal(20_000, 6, 3, 43),
     "C4 multienv_fitness_normal 20000x6 E=4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
     "C5 genotype_fitness_normal 200000x8 G=5000": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45),
-    "C5 as ONE of its 8 ranks: genotype_fitness_normal 25000x8 G=626 (200000/8 barcodes; a standalone problem needs an even genotype count)":
-        lambda: synth.genotype_fitness_normal(25_000, 8, 626, 45),
+    "C5 as ONE of its 8 ranks: genotype_fitness_normal 25000x8 G=625 (200000/8 barcodes, 5000/8 genotypes)":
+        lambda: synth.genotype_fitness_normal(25_000, 8, 625, 45),
     "C5 at about the largest size whose state fits one GPU's registers: genotype_fitness_normal 50000x8 G=1250": lambda: synth.genotype_fitness_normal(50_000, 8, 1_250, 45),
     "(no BASELINE config) multienv_replicate_fitness_normal 12000x(6,5,6) E=3": lambda: synth.multienv_replicate_fitness_normal(),
 }
