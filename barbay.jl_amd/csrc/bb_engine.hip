@@ -11,6 +11,7 @@
 #include "bb_block.h"
 #include "bb_persist.h"
 #include "bb_resident.h"
+#include "bb_inst.h"
 #include "bb_hier.h"
 
 #include <algorithm>
@@ -371,41 +372,12 @@ static int launch_check();
 // persistent launch (bb_persist.h)
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_EMU
-typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, int);
 static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false) {
-#ifdef BB_FAST_BUILD   /* experiment builds (tools/ab_persist.py): only the instances the C2 / C4 workloads use */
+#ifdef BB_FAST_BUILD   /* experiment builds (tools/xp.py): only the instances the C2 / C4 workloads use, in this one translation unit */
     if (!xg && nthr > 512 && P == 1 && kind == 0) return k_persist<0, 1, 1024>;
     return nullptr;
 #else
-    if (xg) {                  // sharded tiles are small: one pair per thread only
-        if (P != 1) return nullptr;
-        if (nthr > 512) switch (kind) {
-            case 0: return k_persist<0, 1, 1024, true>;  case 1: return k_persist<1, 1, 1024, true>;
-            case 3: return k_persist<3, 1, 1024, true>;  case 4: return k_persist<4, 1, 1024, true>;
-            default: return nullptr;
-        }
-        switch (kind) {
-        case 0: return k_persist<0, 1, 512, true>;  case 1: return k_persist<1, 1, 512, true>;
-        case 3: return k_persist<3, 1, 512, true>;  case 4: return k_persist<4, 1, 512, true>;
-        default: return nullptr;
-        }
-    }
-    if (nthr > 512) {          // 16 waves per CU: 128 VGPRs per lane
-        switch (kind * 10 + P) {
-        case 1: return k_persist<0, 1, 1024>;   case 2: return k_persist<0, 2, 1024>;
-        case 11: return k_persist<1, 1, 1024>;  case 12: return k_persist<1, 2, 1024>;
-        case 31: return k_persist<3, 1, 1024>;  case 32: return k_persist<3, 2, 1024>;
-        case 41: return k_persist<4, 1, 1024>;  case 42: return k_persist<4, 2, 1024>;
-        default: return nullptr;
-        }
-    }
-    switch (kind * 10 + P) {   // <= 8 waves per CU: 256 VGPRs per lane, more pairs per thread
-    case 1: return k_persist<0, 1, 512>;   case 2: return k_persist<0, 2, 512>;   case 3: return k_persist<0, 3, 512>;   case 4: return k_persist<0, 4, 512>;
-    case 11: return k_persist<1, 1, 512>;  case 12: return k_persist<1, 2, 512>;  case 13: return k_persist<1, 3, 512>;  case 14: return k_persist<1, 4, 512>;
-    case 31: return k_persist<3, 1, 512>;  case 32: return k_persist<3, 2, 512>;  case 33: return k_persist<3, 3, 512>;  case 34: return k_persist<3, 4, 512>;
-    case 41: return k_persist<4, 1, 512>;  case 42: return k_persist<4, 2, 512>;  case 43: return k_persist<4, 3, 512>;  case 44: return k_persist<4, 4, 512>;
-    default: return nullptr;
-    }
+    return bb_persist_instance(kind, P, nthr, xg);
 #endif
 }
 #endif
@@ -417,7 +389,6 @@ static int uniform_T(const DevModel& M) {
 }
 
 #ifndef BB_EMU
-typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
 static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
 #ifdef BB_FAST_BUILD
     if (xg) return nullptr;
@@ -429,36 +400,13 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
     if (nthr > 512 && P == 1 && kind == 2) return T == 8 ? k_res<2, 1, 1024, false, 8> : k_res<2, 1, 1024, false>;
     return nullptr;
 #else
-    // the BASELINE shapes' time-point counts as compile-time constants (the unit threads then read whole rows at once), in the
-    // geometries those workloads and their shards use; everything else reads T from the descriptor
-#define BR_T(K, PP, NT, TT) if (kind == (K) && P == (PP) && T == (TT)) return xg ? k_res<K, PP, NT, true, TT> : k_res<K, PP, NT, false, TT>;
-    if (nthr > 512) { BR_T(0, 1, 1024, 8) BR_T(0, 1, 1024, 6) BR_T(1, 1, 1024, 8) BR_T(1, 1, 1024, 6) BR_T(2, 1, 1024, 8) }
-    else if (nthr > 256) { BR_T(0, 1, 512, 8) BR_T(0, 2, 512, 8) BR_T(1, 1, 512, 6) BR_T(1, 2, 512, 6) BR_T(2, 2, 512, 8) BR_T(2, 3, 512, 8) BR_T(3, 2, 512, 6) BR_T(3, 3, 512, 6) BR_T(4, 3, 512, 6) }
-#undef BR_T
-#define BR_CASE(K, PP, NT) case (K) * 10 + (PP): return xg ? k_res<K, PP, NT, true> : k_res<K, PP, NT, false>;
-    if (nthr > 512) {          // 16 waves per CU: 128 registers per lane
-        switch (kind * 10 + P) {
-            BR_CASE(0, 1, 1024) BR_CASE(0, 2, 1024) BR_CASE(1, 1, 1024) BR_CASE(1, 2, 1024) BR_CASE(2, 1, 1024) BR_CASE(3, 1, 1024) BR_CASE(4, 1, 1024)
-            default: return nullptr;
-        }
+    switch (kind) {
+    case 0: return bb_res_instance_k0(P, nthr, xg, T);
+    case 1: return bb_res_instance_k1(P, nthr, xg, T);
+    case 2: return bb_res_instance_k2(P, nthr, xg, T);
+    case 3: return bb_res_instance_k3(P, nthr, xg, T);
+    default: return bb_res_instance_k4(P, nthr, xg, T);
     }
-    if (nthr > 256) {          // 8 waves per CU: 256 registers per lane
-        switch (kind * 10 + P) {
-            BR_CASE(0, 1, 512) BR_CASE(0, 2, 512) BR_CASE(0, 3, 512) BR_CASE(1, 1, 512) BR_CASE(1, 2, 512) BR_CASE(1, 3, 512)
-            BR_CASE(2, 1, 512) BR_CASE(2, 2, 512) BR_CASE(2, 3, 512)
-            BR_CASE(3, 1, 512) BR_CASE(3, 2, 512) BR_CASE(3, 3, 512) BR_CASE(4, 1, 512) BR_CASE(4, 2, 512) BR_CASE(4, 3, 512)
-            default: return nullptr;
-        }
-    }
-    switch (kind * 10 + P) {   // 4 waves per CU: 512 registers per lane
-        BR_CASE(0, 1, 256) BR_CASE(0, 2, 256) BR_CASE(0, 3, 256) BR_CASE(0, 4, 256)
-        BR_CASE(1, 1, 256) BR_CASE(1, 2, 256) BR_CASE(1, 3, 256) BR_CASE(1, 4, 256)
-        BR_CASE(2, 1, 256) BR_CASE(2, 2, 256) BR_CASE(2, 3, 256) BR_CASE(2, 4, 256)
-        BR_CASE(3, 1, 256) BR_CASE(3, 2, 256) BR_CASE(3, 3, 256) BR_CASE(3, 4, 256)
-        BR_CASE(4, 1, 256) BR_CASE(4, 2, 256) BR_CASE(4, 3, 256) BR_CASE(4, 4, 256)
-        default: return nullptr;
-    }
-#undef BR_CASE
 #endif
 }
 #endif

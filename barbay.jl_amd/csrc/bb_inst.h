@@ -1,0 +1,18 @@
+// bb_inst.h -- lookup of the resident kernels' template instances.  The instances (about 140 of them, ~1.5 s of hipcc each) are
+// spread over several translation units (bb_inst_*.hip) that __graft_entry__.build_hip compiles in parallel; bb_engine.hip only
+// calls these functions.  (Experiment builds, -DBB_FAST_BUILD, keep a handful of instances inside bb_engine.hip itself.)
+#pragma once
+#include "bb_resident.h"
+
+#ifndef BB_EMU
+typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, int);
+typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
+#define BB_INST __attribute__((visibility("hidden")))
+BB_INST bb_persist_kernel bb_persist_instance(int kind, int P, int nthr, bool xg);
+// k_res<KIND, P, NT, XG, TT>: T = the model's common time-point count (0: replicates differ), compile-time in the BASELINE shapes
+BB_INST bb_res_kernel bb_res_instance_k0(int P, int nthr, bool xg, int T);
+BB_INST bb_res_kernel bb_res_instance_k1(int P, int nthr, bool xg, int T);
+BB_INST bb_res_kernel bb_res_instance_k2(int P, int nthr, bool xg, int T);
+BB_INST bb_res_kernel bb_res_instance_k3(int P, int nthr, bool xg, int T);
+BB_INST bb_res_kernel bb_res_instance_k4(int P, int nthr, bool xg, int T);
+#endif

@@ -11,21 +11,25 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.environ.get("LIB") or os.path.join(ROOT, "barbay.jl_amd", "lib", "libbarbay_hip.so")
 data = open(lib, "rb").read()
-o = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
-n = struct.unpack_from("<Q", data, o + 24)[0]
-p = o + 32
-co = None
-for _ in range(n):
-    off, size, tl = struct.unpack_from("<QQQ", data, p)
-    p += 24
-    trip = data[p:p + tl].decode()
-    p += tl
-    if "gfx950" in trip:
-        co = data[o + off:o + off + size]
-with tempfile.NamedTemporaryFile(suffix=".co") as f:
-    f.write(co)
-    f.flush()
-    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
+notes = ""
+pos = 0
+while True:                     # one offload bundle per translation unit of the library
+    o = data.find(b"__CLANG_OFFLOAD_BUNDLE__", pos)
+    if o < 0:
+        break
+    pos = o + 24
+    n = struct.unpack_from("<Q", data, o + 24)[0]
+    p = o + 32
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", data, p)
+        p += 24
+        trip = data[p:p + tl].decode()
+        p += tl
+        if "gfx950" in trip and size:
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(data[o + off:o + off + size])
+                f.flush()
+                notes += subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
 want = sys.argv[1] if len(sys.argv) > 1 else ""
 for e in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
     g = lambda k: re.search(r"\." + k + r":\s+(\S+)", e)
