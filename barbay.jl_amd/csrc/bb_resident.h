@@ -178,6 +178,7 @@ struct BRSt {
     int thoff[P];                       // hierarchical models: stage index of a unit minus thoff = index of its theta (r NB E_)
     unsigned cnt[P][2];                 // loglambda: the two counts
     bb_f4 lo[P];                        // low-order parts of the four running window sums (bb_opt_apply)
+    bb_d2 gp[P];                        // loglambda pairs: the part of the gradient that needs no totals (br_grad_pre)
 };
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
@@ -398,7 +399,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.am[k] = br_load_pair<KIND>(S.acc_mu, i0, a0, a1);
             st.ao[k] = br_load_pair<KIND>(S.acc_om, i0, a0, a1);
             st.lo[k] = bb_load_lo(S, i0, a0, a1);
-            st.a[k] = st.h[k] = st.z[k] = st.lam[k] = bb_d2{0.0, 0.0};
+            st.a[k] = st.h[k] = st.z[k] = st.lam[k] = st.gp[k] = bb_d2{0.0, 0.0};
         }
     }
     BB_SYNC(cx);
@@ -686,32 +687,108 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
 }
 
 // ---- G: gradients from registers, prior, optimiser, window slot -----------------------------------------------------------
-// Likelihood gradient of a loglambda pair's two latents, everything but lambda re-read from LDS (the staged samples are still
-// there): differences, a = dl - s_eff, r = a - c_t.
+// Likelihood gradient of a loglambda pair's two latents, with r = a - c_t, a = dl - s_eff:
+//   d/dl_t = (R_t - lambda_t) + lambda_t G_t / S_t + w r|_t... - prior
+// Everything that needs no totals -- the counts, the prior term, w a of the three differences (mutants: w comes from the unit's
+// own latent) -- is formed in the EXCHANGE'S SHADOW (br_grad_pre, after the tile's row is out; the SIMDs idle there otherwise) and
+// waits in two registers; after the totals three fused multiply-adds per latent finish it.  Neutral barcodes' precision is a
+// global latent's sample that comes back with the totals: their w a terms are formed afterwards.
+template <int KIND, int P>
+BB_DEV void br_pair_prior(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, bool a0, bool a1, double* pm0, double* iv0, double* pm1, double* iv1) {
+    // Vector form from the segment (LDS, one address per wave mostly), Matrix form per element
+    const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (st.meta[k] >> 12);
+    *pm0 = *pm1 = sgk->pm;
+    *iv0 = *iv1 = sgk->iv;
+    if (sgk->mean_e) {
+        const long long j = st.i0[k] - sgk->blo;
+        if (a0) { *pm0 = sgk->mean_e[j]; *iv0 = sgk->iv_e[j]; }
+        if (a1) { *pm1 = sgk->mean_e[j + 1]; *iv1 = sgk->iv_e[j + 1]; }
+    }
+}
+// the three differences of the pair's latents with their neighbours (minus the units' s_eff for mutants) and the units' precisions
+template <int KIND, int P>
+BB_DEV void br_pair_diffs(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, int buf, double* z0, double* z1,
+                          double* ap, double* am, double* an, double* wp, double* wm, double* wn) {
+    const int meta = st.meta[k];
+    const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT;
+    const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
+    *z0 = zb[0]; *z1 = zb[1];
+    const double zp = hp ? zb[-1] : *z0, zn = hn ? zb[2] : *z1;
+    *ap = *z0 - zp; *am = *z1 - *z0; *an = zn - *z1;
+    *wp = *wm = *wn = 0.0;
+    if (meta & BRM_MUT) {
+        double sp, sm, sn;
+        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &sm, wm);
+        if (KIND == 1 || KIND == 4) {
+            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], KIND >= 3 ? st.thoff[k] : 0, &sp, wp);
+            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, wn);
+        } else { sp = sn = sm; *wp = *wn = *wm; }
+        *ap -= sp; *am -= sm; *an -= sn;
+    }
+}
+// (Only where the pair state leaves room: one pair slot per thread, fitness / multienv kinds -- C2 15.4 -> 15.1 us per step; with
+//  three slots the two extra registers per slot spill, C3 22.7 -> 24.6 us.)
+template <int KIND, int P> BB_DEV constexpr bool br_has_pre() { return P == 1 && KIND <= 1; }
+template <int KIND, int P>
+BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
+    if (!br_has_pre<KIND, P>()) return;
+    const double* lds = cx.lds;
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
+            const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT;
+            double pm0, iv0, pm1, iv1, z0, z1, ap, am, an, wp, wm, wn;
+            br_pair_prior<KIND>(lds, Y, st, k, true, true, &pm0, &iv0, &pm1, &iv1);
+            br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);
+            double A0 = ((double)st.cnt[k][0] - st.lam[k].x) - (z0 - pm0) * iv0;
+            double A1 = ((double)st.cnt[k][1] - st.lam[k].y) - (z1 - pm1) * iv1;
+            if (meta & BRM_MUT) {
+                const double ma = wm * am;
+                A0 += ma - (hp ? wp * ap : 0.0);
+                A1 += (hn ? wn * an : 0.0) - ma;
+            }
+            st.gp[k] = bb_d2{A0, A1};
+        }
+    }
+}
 template <int KIND, int P>
 BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, int buf, double* g0, double* g1) {
     const BBLds& L = Y.L;
     const int meta = st.meta[k], pt = st.pt[k];
-    const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
-    const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
-    const double z0 = zb[0], z1 = zb[1];
-    const double zp = hp ? zb[-1] : z0, zn = hn ? zb[2] : z1;
-    double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
-    if (mut) {
-        double sp, sm, sn;
-        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &sm, &wm);
+    const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT;
+    const double cp = hp ? lds[L.cc + pt - 1] : 0.0, cm = lds[L.cc + pt], cn = hn ? lds[L.cc + pt + 1] : 0.0;
+    if (!br_has_pre<KIND, P>()) {    // everything here, after the totals
+        double pm0, iv0, pm1, iv1, z0, z1, ap, am, an, wp, wm, wn;
+        br_pair_prior<KIND>(lds, Y, st, k, true, true, &pm0, &iv0, &pm1, &iv1);
+        br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);
+        if (!(meta & BRM_MUT)) { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
+        const double rp_ = hp ? wp * (ap - cp) : 0.0, rm_ = wm * (am - cm), rn_ = hn ? wn * (an - cn) : 0.0;
+        const double l0 = st.lam[k].x, l1 = st.lam[k].y;
+        *g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm_ - rp_ - (z0 - pm0) * iv0;
+        *g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn_ - rm_ - (z1 - pm1) * iv1;
+        return;
+    }
+    double rp, rm, rn;               // what the totals add to w r of the three differences
+    if (meta & BRM_MUT) {
+        double s_, wp, wm, wn;
+        br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &s_, &wm);
         if (KIND == 1 || KIND == 4) {
-            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], KIND >= 3 ? st.thoff[k] : 0, &sp, &wp);
-            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
-        } else { sp = sn = sm; wp = wn = wm; }
-        ap -= sp; am -= sm; an -= sn;
-    } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
-    const double rp = hp ? wp * (ap - lds[L.cc + pt - 1]) : 0.0;
-    const double rm = wm * (am - lds[L.cc + pt]);
-    const double rn = hn ? wn * (an - lds[L.cc + pt + 1]) : 0.0;
-    const double l0 = st.lam[k].x, l1 = st.lam[k].y;
-    *g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm - rp;
-    *g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn - rm;
+            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][0], KIND >= 3 ? st.thoff[k] : 0, &s_, &wp);
+            br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &s_, &wn);
+        } else { wp = wn = wm; }
+        rp = -(wp * cp); rm = -(wm * cm); rn = -(wn * cn);
+    } else {
+        double z0, z1, ap, am, an, wp, wm, wn;
+        br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);
+        rp = hp ? lds[L.wbar + pt - 1] * (ap - cp) : 0.0;
+        rm = lds[L.wbar + pt] * (am - cm);
+        rn = hn ? lds[L.wbar + pt + 1] * (an - cn) : 0.0;
+    }
+    *g0 = fma(st.lam[k].x, lds[Y.iG + pt], st.gp[k].x) + (rm - rp);
+    *g1 = fma(st.lam[k].y, lds[Y.iG + pt + 1], st.gp[k].y) + (rn - rm);
 }
 
 // TT > 0: the number of time points is a compile-time constant -- the unit threads then fetch their barcodes' whole rows at once
@@ -747,18 +824,10 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             const int kind = meta & 15;
             if (KIND == 2 && (kind == SK_TH_R) != (pass == 1)) continue;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
-            // prior of the pair's two latents: Vector form from the segment (LDS, one address per wave mostly), Matrix form per element
-            double pm0 = sgk->pm, pm1 = pm0, iv0 = sgk->iv, iv1 = iv0;
-            if (sgk->mean_e) {
-                const long long j = st.i0[k] - sgk->blo;
-                if (a0) { pm0 = sgk->mean_e[j]; iv0 = sgk->iv_e[j]; }
-                if (a1) { pm1 = sgk->mean_e[j + 1]; iv1 = sgk->iv_e[j + 1]; }
-            }
+            double pm0 = 0.0, pm1 = 0.0, iv0 = 0.0, iv1 = 0.0;       // (loglambda: the prior term is in st.gp already)
+            if (kind != SK_L) br_pair_prior<KIND>(lds, Y, st, k, a0, a1, &pm0, &iv0, &pm1, &iv1);
             double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
             if (kind == SK_L) {
-                const double* zb = zbuf + st.zoff[k];
-                z0 = zb[0]; z1 = zb[1];
                 br_l_grad<KIND>(lds, Y, st, k, buf, &g0, &g1);
             } else if (KIND == 2 && kind == SK_TH_R) {
                 const double* stg = lds + buf * Y.SU;
@@ -900,6 +969,7 @@ BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, con
     // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
     br_prefetch_slot<P>(cx, M, S, A, Y, stv, step);
+    br_grad_pre<KIND, P>(cx, Y, stv, (int)(step & 1));          // what of this step's gradient needs no totals
     br_draw_ahead<KIND, P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
 }
 template <bool XG>
