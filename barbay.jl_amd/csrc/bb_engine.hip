@@ -223,6 +223,7 @@ struct bb_handle {
     size_t lds_doubles_p0 = 0;         // ... of the resident launch (adds the lambda table)
     size_t lds_doubles_p = 0;          // ... plus the drawn-ahead normals and the cached counts (16 + 8 B per pair)
     long long b_lo = 0, b_hi = 0;      // barcode shard
+    int res_ng = 8;                    // k_res: groups of the exchange's first hop (RunArgs.ng)
     int cus = 256;                     // compute units of the device (one resident workgroup each)
     int g_lo = 0, g_hi = 0;            // genotype model: the genotypes whose theta this shard owns (all of them unless cut at genotype boundaries)
     std::vector<int> geno_ptr_h;       // genotype model: CSR offsets over genotypes (sorted geno_idx: first mutant of every genotype)
@@ -445,7 +446,7 @@ static bool build_geno_tiles(const bb_handle* h, int NB, int NBL, std::vector<lo
     tg.clear();
     long long b = h->b_lo;
     while (b < h->b_hi) {
-        const int cap = (NBL > 0 && tb.size() < (size_t)BB_NG) ? NBL : NB;
+        const int cap = (NBL > 0 && tb.size() < (size_t)h->res_ng) ? NBL : NB;
         long long e = std::min<long long>(b + cap, h->b_hi);
         if (e < h->b_hi && e > M.nn) {
             e = M.nn + ptr[(size_t)geno_of(e - M.nn)];       // back to the first mutant of the genotype the cut fell into
@@ -470,17 +471,27 @@ static bool try_resident(bb_handle* h) {
     // tile map: leaders (tiles 0 .. 7) hold `frac` of a tile's barcodes (br_tile); BB_TUNE_LEAD=100 keeps all tiles alike
     int NB = h->NB, NBL = 0, nblk = h->nblk;
     const long long nbar = std::max<long long>(h->b_hi - h->b_lo, 1);
+    // groups of the exchange's first hop: 16 on one GPU where the grid is large and the tile has two thread groups for the consume
+    // (bbp_consume<.., WIDE>); the cross-GPU inbox protocol is laid out for 8.  BB_TUNE_NG overrides (8 or 16).
+    {
+        const int KK = h->M.K + 2 * h->M.nt1;
+        int ng = (!h->p2p_on && h->nblk >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)) ? 16 : 8;
+        if ((ev = getenv("BB_TUNE_NG")) && (atoi(ev) == 8 || (atoi(ev) == 16 && !h->p2p_on && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)))) ng = atoi(ev);
+        h->res_ng = ng;
+    }
+    const int NGh = h->res_ng;
     int pct = (ev = getenv("BB_TUNE_LEAD")) ? atoi(ev) : 65;
     if (pct < 10 || pct > 100) pct = 100;
     const bool nb_fixed = getenv("BB_TUNE_NB") != nullptr;
-    if (pct < 100 && h->nblk >= 16 && (!nb_fixed || ev)) {
+    ev = getenv("BB_TUNE_LEAD");
+    if (pct < 100 && h->nblk >= 2 * NGh && (!nb_fixed || ev)) {
         if (!nb_fixed) {
-            const double tiles = (double)h->nblk - (double)BB_NG * (1.0 - pct / 100.0);      // in units of a full tile
+            const double tiles = (double)h->nblk - (double)NGh * (1.0 - pct / 100.0);      // in units of a full tile
             NB = (int)std::ceil((double)nbar / tiles);
         }
         NBL = std::max(1, (int)(NB * (pct / 100.0)));
-        const long long rest = nbar - (long long)BB_NG * NBL;
-        nblk = BB_NG + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
+        const long long rest = nbar - (long long)NGh * NBL;
+        nblk = NGh + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
         const long long p_uni = (br_tile_span(h->M, h->NB, true) + h->nthr - 1) / h->nthr, p_new = (br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr;
         // stay uniform where rounding pushed the map over the grid that fits, or the slightly larger tiles need another pair slot
         if (nblk > h->nblk + (nb_fixed ? 8 : 0) || p_new > p_uni) { NB = h->NB; NBL = 0; nblk = h->nblk; }
@@ -614,7 +625,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
             bbp_draw_ahead<KIND, PP>(cx, h->M, A, h->NB, st + (size_t)b * h->nthr, step + 1);
         }
     } else if (phase == 2) {
-        for (int g = 0; g < bbp_groups(h->nblk); ++g) {
+        for (int g = 0; g < bbp_groups(A); ++g) {
             BBCtx cx = cxof(g);
             if (xg) bbp_leader_reduce<true>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
             else bbp_leader_reduce<false>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
@@ -647,7 +658,7 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
     const unsigned long long step = (unsigned long long)(h->step + it);
     const int buf = (int)(step & 1);
     const bool xg = h->p2p_on;
-    for (int b = 0; b < (phase == 2 ? bbp_groups(h->res_nblk) : h->res_nblk); ++b) {
+    for (int b = 0; b < (phase == 2 ? bbp_groups(A) : h->res_nblk); ++b) {
         BBCtx cx = cxof(b);
         BRSt<PP>* sb = st + (size_t)b * h->nthr;
         if (phase == 0) {
@@ -723,7 +734,7 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
         bb_handle* h = hs[i];
         es[i].h = h;
         es[i].A = make_args(h, h->step, 0, 1, true, false);
-        if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; }
+        if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; es[i].A.ng = h->res_ng; }
         es[i].lds.assign((size_t)std::max(h->nblk, h->res_nblk) * (h->lds_doubles_p + 64), 0.0);
         es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
@@ -766,7 +777,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
     bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M)) : nullptr;
-    if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; }
+    if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; A.ng = h->res_ng; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
@@ -1098,8 +1109,8 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     }
 #endif
     BB_TRY(dalloc(h, &S.prow, (size_t)(h->nblk + 8) * (M.K + 2 * M.nt1)));      // (+ 8: k_res's own tile map may need a few tiles more)
-    BB_TRY(dalloc(h, &S.xrow, (size_t)2 * BB_NG * (M.K + 2 * M.nt1)));
-    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 2 * BB_NG)));
+    BB_TRY(dalloc(h, &S.xrow, (size_t)2 * BB_NG_MAX * (M.K + 2 * M.nt1)));
+    BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 2 * BB_NG_MAX)));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));
@@ -1178,6 +1189,7 @@ static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, 
     A.spin_limit = 1u << 23;                  // ~1 us per poll: seconds, not milliseconds
     A.nblk = h->nblk;
     A.nblk_alloc = h->nblk;
+    A.ng = 8;
     A.par = (int)(step & 1);
     A.sample = sample;
     A.S = S;

@@ -310,10 +310,8 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
 // row of the previous step, which the leaders publish only after reading all member rows).  Every poll is bounded.
 typedef unsigned long long bb_u64;
 
-#ifndef BB_NG
-#define BB_NG 8            /* groups of the exchange's first hop on one GPU (the cross-GPU inbox protocol is laid out for 8) */
-#endif
-BB_DEV int bbp_groups(int nblk) { return nblk < BB_NG ? nblk : BB_NG; }
+#define BB_NG_MAX 16       /* groups of the exchange's first hop: RunArgs.ng = 8 (the cross-GPU inbox protocol is laid out for 8) or 16 */
+BB_DEV int bbp_groups(const RunArgs& A) { return A.nblk < A.ng ? A.nblk : A.ng; }
 
 // Poll *word until it equals epoch; false = gave up (timeout word set).
 BB_DEV bool bb_wait_word(const unsigned* word, unsigned epoch, unsigned* tmo, unsigned limit) {
@@ -419,7 +417,7 @@ BB_DEV void bbp_publish_row(BBCtx& cx, const DevModel& M, const DevState& S, con
 template <bool XG = false>
 BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par,
                               unsigned epoch, int* ok, unsigned abs_epoch = 0u) {
-    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk), g = cx.block;
+    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A), g = cx.block;
     const int members = (A.nblk - g + NG - 1) / NG;
     BB_PASS(cx, tid) {
         if (tid < members && !bb_wait_word(S.rdy + 32 * (g + tid * NG), epoch, S.gbar + 1, A.spin_limit)) *ok = 0;
@@ -455,11 +453,72 @@ BB_DEV void bbp_leader_reduce(BBCtx& cx, const DevModel& M, const DevState& S, c
 }
 
 // every tile: wait for the NG group rows, add them in group order -> totals in lds[L.wk], global samples in lds[L.zgl]
-template <bool XG = false>
+// WIDE (k_res on one GPU): up to 16 groups, read by two thread groups of KKP = 64 or 128 lanes -- half h polls and reads groups
+// [8 h, 8 h + 8), eight loads in flight per lane as in the narrow form (sixteen would raise the kernel's register peak: measured,
+// the G pass doubled); half 1's partial sums cross through LDS and one workgroup barrier, half 0 adds them: (g0 + .. + g7) +
+// (g8 + .. + g15).  A leader then has 16 members: one round of loads instead of two.
+template <bool XG = false, bool WIDE = false>
 BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par,
                         unsigned epoch, int* ok, unsigned abs_epoch = 0u) {
     double* lds = cx.lds;
-    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A.nblk);
+    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A);
+    if (WIDE && !XG) {
+        const int KKP = KK <= 64 ? 64 : 128;
+        BB_PASS(cx, tid) {
+            const int half = tid / KKP, k = tid - half * KKP, g0 = 8 * half;
+            if (half < 2 && k < 8 && g0 + k < NG && !bb_wait_word(S.rdy + 32 * (A.nblk + par * NG + g0 + k), epoch, S.gbar + 1, A.spin_limit)) *ok = 0;
+        }
+        if (KK <= 64) {
+            // each half is one wave: it has left its poll loop before it loads (the wait also keeps the compiler from hoisting the loads)
+#ifndef BB_EMU
+            if (threadIdx.x < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        } else {
+            BB_SYNC(cx);
+        }
+        BB_STAMP(cx, S, 1);
+        BB_PASS(cx, tid) {
+            const int half = tid / KKP, k = tid - half * KKP, g0 = 8 * half;
+            if (half == 1 && k < KK) {
+                double v[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) v[g] = g0 + g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g0 + g) * KK + k) : 0.0;
+                double s = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) s += v[g];
+                lds[L.red + k] = s;
+            }
+        }
+        double s0 = 0.0;
+        BB_PASS(cx, tid) {
+            if (tid < KK) {
+                double v[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) v[g] = g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g) * KK + tid) : 0.0;
+                double s = 0.0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) s += v[g];
+#ifdef BB_EMU
+                lds[L.red + KKP + tid] = s;
+#else
+                s0 = s;
+#endif
+            }
+        }
+        BB_SYNC(cx);
+        BB_PASS(cx, tid) {
+            if (tid < KK) {
+#ifdef BB_EMU
+                s0 = lds[L.red + KKP + tid];
+#endif
+                const double s = s0 + (NG > 8 ? lds[L.red + tid] : 0.0);
+                if (tid < M.K) bb_put_total(M, L, lds, tid, s);
+                else lds[L.zgl + (tid - M.K)] = s;
+            }
+        }
+        if (!(KK <= 64 && M.Ttot <= 64)) BB_SYNC(cx);
+        return;
+    }
     if (XG) {
         // the 8 x world rows of this rank's own inbox (slot order = (source rank, group) = summation order)
         const int rows = 8 * A.world;
@@ -510,12 +569,12 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
     BB_STAMP(cx, S, 1);
     BB_PASS(cx, tid) {
         for (int k = tid; k < KK; k += cx.nthr) {
-            double v[BB_NG];
+            double v[8];
 #pragma unroll
-            for (int g = 0; g < BB_NG; ++g) v[g] = g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g) * KK + k) : 0.0;
+            for (int g = 0; g < 8; ++g) v[g] = g < NG ? bb_ld<true>(S.xrow + ((long long)par * NG + g) * KK + k) : 0.0;
             double s = 0.0;
 #pragma unroll
-            for (int g = 0; g < BB_NG; ++g) s += v[g];
+            for (int g = 0; g < 8; ++g) s += v[g];
             if (k < M.K) bb_put_total(M, L, lds, k, s);
             else lds[L.zgl + (k - M.K)] = s;
         }
@@ -657,7 +716,7 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
             const int par = (int)(step & 1);
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
             bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight
-            if ((int)blockIdx.x < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);
+            if ((int)blockIdx.x < bbp_groups(A)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);
             bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
             bbp_residual_ahead<KIND>(cx, M, NB, A);                    // ... and the totals-independent half of the residuals is tabulated
             bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);

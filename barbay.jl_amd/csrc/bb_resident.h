@@ -155,7 +155,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     Y.eps = Y.hbuf + 4 * P * NT;
     { const int need = racc_total > 6 * P * NT ? racc_total : 6 * P * NT; o += need; }
     L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;     // staging of the cross-GPU inbox rows (bbp_consume<true>): in use while the slot / normals wait
-    L.red = o;     o += KK + 16;
+    L.red = o;     o += 2 * 128 + KK + 16;          // (bbp_consume<.., WIDE>: the second half's partial sums)
     (void)lmax;
     L.total = Y.total = (o + 1) & ~1;
     return Y;
@@ -202,7 +202,7 @@ template <int KIND> BB_DEV void br_store_pair(double* base, long long i0, bool a
 // rows arrive, and the group rows appear one draw (~5 k cycles) sooner for all tiles.
 BB_DEV BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
     if (A.nbl <= 0) return bb_tile(M, A, block, NB);
-    const int nlead = A.nblk < BB_NG ? A.nblk : BB_NG;
+    const int nlead = bbp_groups(A);
     BBTile t;
     t.NB = NB;
     const int cap = block < nlead ? A.nbl : NB;
@@ -977,13 +977,13 @@ BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const 
     const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
     // (fetching the members' rows in one round trip -- two waves, 16 members each, partial sums through LDS -- measured SLOWER,
     //  as round 1 had found for k_persist: 7.6 k cycles against 4.8 k for the leader's read + sum + publish)
-    if (cx.block < bbp_groups(A.nblk)) bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+    if (cx.block < bbp_groups(A)) bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
 }
 template <int KIND, int P, bool XG>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                             unsigned long long step, int* ok_slot) {
     const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
-    bbp_consume<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+    bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
     br_finish<KIND>(cx, M, S, Y);
 }
 

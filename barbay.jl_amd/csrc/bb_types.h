@@ -97,6 +97,7 @@ struct RunArgs {
     unsigned spin_limit;              // polls of one ready word before a resident launch gives up (the first launch of a sharded run gets more)
     int nblk;                         // blocks of the barcode grid
     int nblk_alloc;                   // tiles the exchange / stamp buffers were sized for (+ 8)
+    int ng;                           // groups of the exchange's first hop (8; k_res on one GPU: 16 where the tile has the threads for it)
     int nbl;                          // k_res: barcodes of each of the first min(8, nblk) tiles -- the exchange's group leaders get smaller tiles (0: all tiles alike)
     int par;                          // which ctr[] word holds the current step
     int sample, S;

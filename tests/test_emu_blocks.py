@@ -101,6 +101,18 @@ def test_owner_computes_launch_smaller_leader_tiles(emu_lib, monkeypatch, lead):
     c.case_p2p_resident(emu_lib, "fitness_T6", 2)
 
 
+@pytest.mark.parametrize("name,nb,nthr", [("fitness_T6", 16, 128), ("multienv_T8", 8, 256), ("replicate_R3", 8, 256), ("genotype_runs", 24, 128)])
+def test_owner_computes_launch_sixteen_groups(emu_lib, monkeypatch, name, nb, nthr):
+    """The exchange's first hop with 16 groups (what a full single-GPU grid uses): 16 leaders, every tile's consume split over two
+    thread groups (groups 0-7 and 8-15, partial sums through LDS); totals and results as with 8."""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_NG", "16")
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
+    monkeypatch.setenv("BB_TUNE_LEAD", "50")
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
+
+
 @pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
 def test_owner_computes_launch_genotype(emu_lib, name):
     """Genotype model under k_res: mutants grouped by genotype, tiles cut at genotype boundaries own their genotypes' theta
