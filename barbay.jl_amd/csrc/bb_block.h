@@ -395,11 +395,13 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
             s = s > 0.0 ? s : 0.0;            // (an all-zero window can come out as -1e-60)
         }
         *acc = s;
-        upd = d * (A.eta * bb_rcp(A.tau + bb_sqrt(s)));
+        bb_cdouble* oc = bb_tab(S.optc);
+        upd = d * (oc[0] * bb_rcp(oc[1] + bb_sqrt(s)));
     } else {            // DecayedADAGrad: acc = post*acc + pre*d^2; d *= eta / (sqrt(acc) + 1e-8)
-        const double a = A.post * (*acc) + A.pre * d * d;
+        bb_cdouble* oc = bb_tab(S.optc);
+        const double a = oc[3] * (*acc) + oc[2] * d * d;
         *acc = a;
-        upd = d * (A.eta * bb_rcp(bb_sqrt(a) + 1e-8));
+        upd = d * (oc[0] * bb_rcp(bb_sqrt(a) + 1e-8));
     }
     *p -= upd;
 }

@@ -1082,6 +1082,13 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     BB_TRY(dalloc(h, &S.acc_mu, D + 2));
     BB_TRY(dalloc(h, &S.acc_om, D + 2));
     BB_TRY(dalloc(h, &S.accl, 2 * D + 8));
+    {
+        double* oc = nullptr;
+        const double v[8] = {opts->eta, opts->tau, opts->pre, opts->post, 0, 0, 0, 0};
+        BB_TRY(dalloc(h, &oc, 8));
+        BB_TRY(h2d(oc, v, sizeof v, h->stream));
+        S.optc = oc;
+    }
     BB_TRY(dalloc(h, &S.gacc_mu, D + 2));
     BB_TRY(dalloc(h, &S.gacc_om, D + 2));
     BB_TRY(dalloc(h, &h->bak_mu, D + 2));

@@ -58,6 +58,9 @@ struct DevState {
     double *zsv, *asv, *hsv;          // [D] per-sample scratch: z, eps*sigmoid(omega) (= dz/domega), sigmoid/softplus (= dH/domega)
     double *acc_mu, *acc_om;          // [D] optimiser accumulators
     double *hist;                     // [W][2][Dp] TruncatedADAGrad window of squared gradients
+    const double *optc;               // [8] the optimiser's constants {eta, tau, pre, post}: read by scalar loads at every update (bb_opt_apply) --
+                                      // as kernel arguments they sat in VGPR lanes inside the resident launches' step loop (the loop holds more
+                                      // uniform values than there are SGPRs) and every update paid eight v_readlane_b32 for them
     float *accl;                      // [2 D] low-order parts of the running window sums: (acc_mu[i], accl[2 i]) and (acc_om[i], accl[2 i + 1]) are
                                       // compensated (two-sum) accumulators, bb_opt_apply
     double *gacc_mu, *gacc_om;        // [D] S > 1 accumulation / gradient export
