@@ -386,9 +386,11 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
             for (int j = 0; j < A.W; ++j) s += (j == w.slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
             *lo = 0.f;
         } else {
-            double t, e1, u, e2;
+            double t, e1;
             bb_two_sum(*acc, n2, &t, &e1);
-            bb_two_sum(t, -old_slot, &u, &e2);
+            // t >= old_slot (the sum holds that slot's value among its non-negative terms): the fast form of the error-free
+            // sum is exact here -- three additions instead of six
+            const double u = t - old_slot, e2 = (t - u) - old_slot;
             const double l = (double)*lo + (e1 + e2);
             s = u + l;
             *lo = (float)(l - (s - u));

@@ -296,9 +296,9 @@ int port_run(const port_model* M, double* mu, double* omega, int64_t first_step,
                     for (int k = 0; k < window; ++k) sacc += hist[(int64_t)k * 2 * D + j];
                     lo[j] = 0.0;
                 } else {
-                    double t, e1, u, e2;
+                    double t, e1;
                     port_two_sum(acc[j], n2, &t, &e1);
-                    port_two_sum(t, -old, &u, &e2);
+                    const double u = t - old, e2 = (t - u) - old;      /* fast two-sum: t >= old */
                     const double l = lo[j] + (e1 + e2);
                     sacc = u + l;
                     lo[j] = (double)(float)(l - (sacc - u));
