@@ -462,7 +462,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
                         unsigned epoch, int* ok, unsigned abs_epoch = 0u) {
     double* lds = cx.lds;
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A);
-    if (WIDE && !XG) {
+    if (WIDE && !XG && A.ng > 8) {      // (the host asks for 16 groups only where KK <= 128 and the tile has 2 KKP threads)
         const int KKP = KK <= 64 ? 64 : 128;
         BB_PASS(cx, tid) {
             const int half = tid / KKP, k = tid - half * KKP, g0 = 8 * half;

@@ -23,6 +23,7 @@ SYNTH = {
     "multienv_T8": ("multienv", dict(B=300, T=8, n_env=4, n_neutral=40)),
     "replicate_T6": ("replicate", dict(B=301, T=6, n_rep=2, n_neutral=1)),                 # hierarchical kinds under k_res
     "replicate_R3": ("replicate", dict(B=400, T=[6, 8, 4], n_rep=3, n_neutral=20)),        # ... ragged (all T_r even)
+    "replicate_R4": ("replicate", dict(B=240, T=[8, 8, 6, 6], n_rep=4, n_neutral=12)),           # K + 2 nt1 = 198 moment-row entries: more than a small tile's threads
     "multienv_replicate_T6": ("multienv_replicate", dict(B=150, T=6, n_rep=2, n_env=2, n_neutral=10)),
     "multienv_replicate_R3": ("multienv_replicate", dict(B=300, T=[6, 4, 8], n_rep=3, n_env=3, n_neutral=7)),
     "multienv": ("multienv", dict(B=600, T=7, n_env=3, n_neutral=11)),

@@ -218,6 +218,19 @@ def test_owner_computes_launch_geometries(hip_lib, monkeypatch, nb, nthr):
     c.case_persistent_equals_two_kernel(hip_lib, "multienv_T8", expect_kernel=2)
 
 
+@pytest.mark.parametrize("nb,nthr,ng", [(0, 0, 0), (16, 128, 16), (8, 256, 16)])
+def test_owner_computes_launch_exchange_shapes(hip_lib, monkeypatch, nb, nthr, ng):
+    """the exchange's first hop: a moment row longer than the two-half consume handles (four replicates, 198 entries: 8 groups,
+    strided form) and 16 groups on small grids (members per leader uneven)"""
+    if nb:
+        monkeypatch.setenv("BB_TUNE_NB", str(nb))
+        monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+        monkeypatch.setenv("BB_TUNE_NG", str(ng))
+    c.case_persistent_equals_two_kernel(hip_lib, "replicate_R4", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(hip_lib, "fitness_T6", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(hip_lib, "multienv_T8", expect_kernel=2)
+
+
 @pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
 def test_owner_computes_launch_genotype(hip_lib, name):
     """Genotype model under k_res (mutants grouped by genotype, tiles own whole genotypes and their theta): same arithmetic as
