@@ -473,6 +473,7 @@ static bool try_resident(bb_handle* h) {
     const long long nbar = std::max<long long>(h->b_hi - h->b_lo, 1);
     // groups of the exchange's first hop: 16 on one GPU where the grid is large and the tile has two thread groups for the consume
     // (bbp_consume<.., WIDE>); the cross-GPU inbox protocol is laid out for 8.  BB_TUNE_NG overrides (8 or 16).
+    if (!h->p2p_on && h->M.K + 2 * h->M.nt1 > h->nthr) return false;      // (bbp_consume<.., WIDE>: one thread per row entry)
     {
         const int KK = h->M.K + 2 * h->M.nt1;
         int ng = (!h->p2p_on && h->nblk >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)) ? 16 : 8;

@@ -462,7 +462,10 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
                         unsigned epoch, int* ok, unsigned abs_epoch = 0u) {
     double* lds = cx.lds;
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A);
-    if (WIDE && !XG && A.ng > 8) {      // (the host asks for 16 groups only where KK <= 128 and the tile has 2 KKP threads)
+    if (WIDE && !XG) {
+        // (the host runs this form only where the tile has a thread per row entry, KK <= nthr, and asks for 16 groups only where
+        //  KK <= 128 and the tile has 2 KKP threads: try_resident.  A strided general form beside or instead of it costs the
+        //  C2 instance 3 %: the step loop is short of scalar registers as it is.)
         const int KKP = KK <= 64 ? 64 : 128;
         BB_PASS(cx, tid) {
             const int half = tid / KKP, k = tid - half * KKP, g0 = 8 * half;

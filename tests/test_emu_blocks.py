@@ -113,15 +113,15 @@ def test_owner_computes_launch_sixteen_groups(emu_lib, monkeypatch, name, nb, nt
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
-@pytest.mark.parametrize("nb,nthr", [(0, 0), (16, 128), (30, 256)])
-def test_owner_computes_launch_long_moment_row(emu_lib, monkeypatch, nb, nthr):
-    """four replicates: the moment row (198 entries) is longer than a small tile has threads and than the two-half consume
-    handles -- the exchange then keeps 8 groups and the strided form"""
+@pytest.mark.parametrize("nb,nthr,kernel", [(0, 0, None), (16, 128, 1), (30, 256, 2)])
+def test_owner_computes_launch_long_moment_row(emu_lib, monkeypatch, nb, nthr, kernel):
+    """four replicates: the moment row has 198 entries -- more than the two-half consume handles (the exchange keeps 8 groups),
+    and on a one-GPU tile with fewer threads than that k_res is not used at all (k_persist's strided consume is)"""
     if nb:
         monkeypatch.setenv("BB_TUNE_NB", str(nb))
         monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
         monkeypatch.setenv("BB_TUNE_NG", "16")          # (asked for, refused by the engine: 198 > 128)
-    c.case_persistent_equals_two_kernel(emu_lib, "replicate_R4", expect_kernel=2)
+    c.case_persistent_equals_two_kernel(emu_lib, "replicate_R4", expect_kernel=kernel)
 
 
 @pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
