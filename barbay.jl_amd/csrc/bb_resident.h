@@ -1011,6 +1011,15 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
         for (; done < nsteps; ++done) {
             const unsigned long long step = step0 + (unsigned long long)done;
             const int buf = (int)(step & 1);
+            // Several pair slots: the pair descriptors are opaque to the compiler at every step.  Otherwise it hoists the ~15
+            // predicates on each of them (kind, valid, mutant, has neighbour ...) out of the step loop as 64-bit lane masks --
+            // scalar registers the loop does not have, so that they lived in VGPR lanes (two v_readlane_b32 per use) and took
+            // vector registers from the pair state: C3's instance 58 -> 9 spilled registers, 22.4 -> 20.1 us per step.  (One
+            // slot of the fitness / multienv kinds: no gain, -0.4 %.)
+            if (P > 1 || KIND >= 2) {
+#pragma unroll
+                for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
+            }
             br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
             br_moments<KIND, P>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_publish<KIND, P>(cx, M, S, A, Y, &st, step);
