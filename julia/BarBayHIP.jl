@@ -78,6 +78,26 @@ end
 const KIND = Dict("fitness_normal" => 0, "multienv_fitness_normal" => 1, "genotype_fitness_normal" => 2,
                   "replicate_fitness_normal" => 3, "multienv_replicate_fitness_normal" => 4)
 
+"""
+    group_genotypes(data; genotype_col=:genotype, neutral_col=:neutral) -> data
+
+Stable reorder of a tidy frame's rows so that the mutant barcodes of one genotype are consecutive (genotypes in order of first
+appearance), to be applied BEFORE `BarBay.utils.data_to_arrays`: the engine's resident launch and its genotype-aligned sharding
+of `genotype_fitness_normal` need `indexin(genotypes, unique(genotypes))` to be non-decreasing (DESIGN.md 3.1, 5).  Results are
+keyed by barcode id, so the order is the caller's to choose.  (`data_to_arrays` keeps barcodes in order of appearance,
+src/utils.jl:692-731.)  Works on any Tables.jl-style object with `getproperty` columns and `data[perm, :]` indexing (DataFrame).
+"""
+function group_genotypes(data; genotype_col::Symbol=:genotype, neutral_col::Symbol=:neutral)
+    g = getproperty(data, genotype_col)
+    neutral = getproperty(data, neutral_col)
+    first_seen = Dict{eltype(g),Int}()
+    for x in g
+        get!(first_seen, x, length(first_seen) + 1)
+    end
+    key = [neutral[i] ? 0 : first_seen[g[i]] for i in eachindex(g)]        # neutrals keep their place in front
+    return data[sortperm(key; alg=MergeSort), :]
+end
+
 # prior kwarg (`VecOrMat{Float64}`) -> (mean, std) vectors kept alive by the caller
 _prior_arrays(p::Vector{Float64}) = ([p[1]], [p[2]])
 _prior_arrays(p::Matrix{Float64}) = (p[:, 1], p[:, 2])

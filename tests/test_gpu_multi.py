@@ -116,15 +116,17 @@ def test_bench_rehearsal_two_ranks_on_one_gpu():
     assert "resident launch" in out["config"]["collective"]
 
 
-def test_one_handle_drives_all_devices(hip_lib, monkeypatch):
-    """bb_advi_opts.n_devices over REAL peers: one process, one handle, hipDeviceEnablePeerAccess inboxes."""
+@pytest.mark.parametrize("case", ["fitness_T6", "genotype_runs"])
+def test_one_handle_drives_all_devices(hip_lib, monkeypatch, case):
+    """bb_advi_opts.n_devices over REAL peers: one process, one handle, hipDeviceEnablePeerAccess inboxes (genotype model: every
+    device owns its genotypes' theta, gathered from the owners at the end of each run)."""
     if _n_gpus() < 2:
         pytest.skip("needs >= 2 GPUs")
     import _cases as c
     n = min(_n_gpus(), 4)
     monkeypatch.setenv("BB_TUNE_NB", "8")
     monkeypatch.setenv("BB_TUNE_NTHR", "512")
-    sp = c.synth("fitness_T6", seed=4)
+    sp = c.synth(case, seed=4)
     from conftest import make_engine
     kw = dict(seed=5, window=4, resum_every=1)
     with make_engine(sp, hip_lib, launch_mode=1, **kw) as e1:
