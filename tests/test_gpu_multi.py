@@ -69,8 +69,9 @@ def test_sharded_over_real_peers(hip_lib, tmp_path, monkeypatch, case, p2p):
     import torch.multiprocessing as mp
     import _cases as c
     from conftest import make_engine
-    world = min(_n_gpus(), 4)
-    monkeypatch.setenv("BB_TUNE_NB", "8")           # >= 8 tiles per rank at 4 ranks (the resident launch's minimum)
+    geno = case == "genotype_runs"
+    world = min(_n_gpus(), 2 if geno else 4)
+    monkeypatch.setenv("BB_TUNE_NB", "24" if geno else "8")   # >= 8 tiles per rank (the resident launch's minimum); a tile holds whole genotypes
     monkeypatch.setenv("BB_TUNE_NTHR", "512")
     steps = 50
     sp = c.synth(case, seed=4)
@@ -80,7 +81,7 @@ def test_sharded_over_real_peers(hip_lib, tmp_path, monkeypatch, case, p2p):
     mp.spawn(_worker, args=(world, _free_port(), case, steps, p2p, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "sharded.npz")
     if p2p:
-        assert bool(got["on"]) and int(got["pairs"]) == 1          # the resident launch over peer-mapped inboxes really ran
+        assert bool(got["on"]) and int(got["pairs"]) >= 1          # the resident launch over peer-mapped inboxes really ran
     assert bool(got["identical"])                                   # replicated global latents: bit-identical on all ranks
     assert np.abs(got["mean"] - m1).max() < 1e-8 and np.abs(got["sigma"] - s1).max() < 1e-8
 
@@ -123,8 +124,8 @@ def test_one_handle_drives_all_devices(hip_lib, monkeypatch, case):
     if _n_gpus() < 2:
         pytest.skip("needs >= 2 GPUs")
     import _cases as c
-    n = min(_n_gpus(), 4)
-    monkeypatch.setenv("BB_TUNE_NB", "8")
+    n = min(_n_gpus(), 4 if case == "fitness_T6" else 2)
+    monkeypatch.setenv("BB_TUNE_NB", "8" if case == "fitness_T6" else "24")     # (a tile must hold whole genotypes; >= 8 tiles per device)
     monkeypatch.setenv("BB_TUNE_NTHR", "512")
     sp = c.synth(case, seed=4)
     from conftest import make_engine
