@@ -48,11 +48,13 @@ def _worker(rank, world, port, case, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["fitness_multi_tile", "replicate_ragged", "multienv"])
+@pytest.mark.parametrize("case", ["fitness_multi_tile", "replicate_ragged", "multienv", "fitness_T6", "multienv_T8", "genotype_runs"])
 def test_two_processes_one_gpu(hip_lib, tmp_path, monkeypatch, case):
+    """(the first three run k_persist's cross-GPU form, the others k_res's; genotype_runs: shards cut at genotype boundaries, every
+    rank owns its genotypes' theta -- no communicator here, so the gather takes theta from its owners)"""
     import _cases as c
     from conftest import make_engine
-    monkeypatch.setenv("BB_TUNE_NB", "16")          # >= 8 tiles per rank; both ranks' small grids fit the one GPU together
+    monkeypatch.setenv("BB_TUNE_NB", "24" if case == "genotype_runs" else "16")   # >= 8 tiles per rank; both ranks' small grids fit the one GPU together
     monkeypatch.setenv("BB_TUNE_NTHR", "512")
     steps = 9
     sp = c.synth(case, seed=4)
