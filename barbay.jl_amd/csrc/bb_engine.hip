@@ -390,9 +390,14 @@ static int uniform_T(const DevModel& M) {
 }
 
 #ifndef BB_EMU
-static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
+static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool ap) {
 #ifdef BB_FAST_BUILD
     if (xg) return nullptr;
+    if (ap) {
+        if (nthr > 512 && P == 1 && kind == 0) return k_res<0, 1, 1024, false, 0, true>;
+        if (nthr > 256 && nthr <= 512 && P == 3 && kind == 3) return k_res<3, 3, 512, false, 0, true>;
+        return nullptr;
+    }
     if (nthr > 512 && P == 1 && kind == 0) return T == 8 ? k_res<0, 1, 1024, false, 8> : k_res<0, 1, 1024, false>;
     if (nthr > 512 && P == 1 && kind == 1) return T == 6 ? k_res<1, 1, 1024, false, 6> : k_res<1, 1, 1024, false>;
     if (nthr > 256 && nthr <= 512 && P == 2 && kind == 0) return T == 8 ? k_res<0, 2, 512, false, 8> : k_res<0, 2, 512, false>;
@@ -402,11 +407,11 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T) {
     return nullptr;
 #else
     switch (kind) {
-    case 0: return bb_res_instance_k0(P, nthr, xg, T);
-    case 1: return bb_res_instance_k1(P, nthr, xg, T);
-    case 2: return bb_res_instance_k2(P, nthr, xg, T);
-    case 3: return bb_res_instance_k3(P, nthr, xg, T);
-    default: return bb_res_instance_k4(P, nthr, xg, T);
+    case 0: return bb_res_instance_k0(P, nthr, xg, T, ap);
+    case 1: return bb_res_instance_k1(P, nthr, xg, T, ap);
+    case 2: return bb_res_instance_k2(P, nthr, xg, T, ap);
+    case 3: return bb_res_instance_k3(P, nthr, xg, T, ap);
+    default: return bb_res_instance_k4(P, nthr, xg, T, ap);
     }
 #endif
 }
@@ -464,10 +469,15 @@ static bool build_geno_tiles(const bb_handle* h, int NB, int NBL, std::vector<lo
 }
 
 // the owner-computes launch (bb_resident.h) where the shape allows it; BB_NO_RES=1 keeps k_persist (A/B runs)
-static bool try_resident(bb_handle* h) {
+// any_parity: also the AP instances (odd time-point counts, odd loglambda offset).  Measured (C2-sized fitness_normal with 7 / 5
+// time points, the fifth model): they are 1 - 5 % SLOWER than k_persist -- parity is a run-time property of every pair there,
+// 45 spilled registers and two Philox draws in divergent lanes -- so setup_persistent asks for them only where k_persist cannot
+// run: the genotype model (whose other choice is the two-kernel step) or after k_persist has refused the shape.
+static bool try_resident(bb_handle* h, bool any_parity) {
     const char* ev = getenv("BB_NO_RES");
     if (ev && atoi(ev) > 0) return false;
     if (!br_eligible(h->M)) return false;
+    if (!any_parity && br_any_parity(h->M)) return false;
     // tile map: leaders (tiles 0 .. 7) hold `frac` of a tile's barcodes (br_tile); BB_TUNE_LEAD=100 keeps all tiles alike
     int NB = h->NB, NBL = 0, nblk = h->nblk;
     const long long nbar = std::max<long long>(h->b_hi - h->b_lo, 1);
@@ -517,7 +527,7 @@ static bool try_resident(bb_handle* h) {
     const BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on);
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
-    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M));
+    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M));
     if (!k) return false;
     const int lds = Y.total * 8;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
@@ -551,7 +561,8 @@ static int setup_persistent(bb_handle* h) {
     else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";   // (k_res's own tile map never has fewer tiles than this one)
     else if (h->o.elbo_every != 0) why = "ELBO recording is on";
     h->res_P = 0;
-    if (!why && want && try_resident(h)) { h->persist_P = h->res_P; return 0; }
+    const bool ap_first = h->M.kind == BB_MODEL_GENOTYPE || (getenv("BB_TUNE_AP") && atoi(getenv("BB_TUNE_AP")) > 0);
+    if (!why && want && try_resident(h, ap_first)) { h->persist_P = h->res_P; return 0; }
     if (!why && h->M.kind == BB_MODEL_GENOTYPE)
         why = h->M.geno_sorted ? "genotype model: no tile map with whole genotypes per tile fits the device" : "genotype model: geno_idx is not in consecutive runs (a tile must hold whole genotypes)";
     int P = 0;
@@ -582,6 +593,10 @@ static int setup_persistent(bb_handle* h) {
     }
 #endif
     if (why) {
+        // k_persist cannot (tile too large for its state, no instance, sharded with more than one pair per thread ...): k_res's
+        // any-parity instances as the second chance
+        const bool structural = h->o.samples_per_step != 1 || h->o.elbo_every != 0 || h->force_reduce || (h->o.world_size != 1 && !h->p2p_on) || (h->p2p_on && h->nblk < 8);
+        if (want && !structural && !ap_first && try_resident(h, true)) { h->persist_P = h->res_P; return 0; }
         if (h->o.launch_mode == 2) return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2 (persistent) not possible: %s", why);
         return 0;
     }
@@ -649,7 +664,7 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     }
 }
 
-template <int KIND, int PP>
+template <int KIND, int PP, bool AP>
 static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nsteps) {
     bb_handle* h = E.h;
     const RunArgs& A = E.A;
@@ -663,12 +678,12 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
         BBCtx cx = cxof(b);
         BRSt<PP>* sb = st + (size_t)b * h->nthr;
         if (phase == 0) {
-            br_prologue<KIND, PP>(cx, h->M, h->S, A, Y, h->res_NB, sb);
-            br_draw_ahead<KIND, PP>(cx, A, Y, sb, (unsigned long long)h->step);
+            br_prologue<KIND, PP, AP>(cx, h->M, h->S, A, Y, h->res_NB, sb);
+            br_draw_ahead<KIND, PP, AP>(cx, A, Y, sb, (unsigned long long)h->step);
         } else if (phase == 1) {
             br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
             br_moments<KIND, PP>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<KIND, PP>(cx, h->M, h->S, A, Y, sb, step);
+            br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, step);
         } else if (phase == 2) {
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);
             else br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
@@ -676,24 +691,25 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             if (xg) br_xchg_consume<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             else br_xchg_consume<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
-            if (uniform_T(h->M) == 8) br_update<KIND, PP, 8>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
-            else if (uniform_T(h->M) == 6) br_update<KIND, PP, 6>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
-            else br_update<KIND, PP>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
+            if (!AP && uniform_T(h->M) == 8) br_update<KIND, PP, 8, false>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
+            else if (!AP && uniform_T(h->M) == 6) br_update<KIND, PP, 6, false>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
+            else br_update<KIND, PP, 0, AP>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
         } else {
-            br_epilogue<KIND, PP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
+            br_epilogue<KIND, PP, AP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
     }
 }
 
 static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long long nsteps) {
     if (E.h->res_P) {
+        const bool ap = br_any_parity(E.h->M);
         auto byP = [&](auto kindc) {
             constexpr int KIND = decltype(kindc)::value;
             switch (E.h->res_P) {
-            case 1: emu_res_phase<KIND, 1>(E, phase, it, nsteps); break;
-            case 2: emu_res_phase<KIND, 2>(E, phase, it, nsteps); break;
-            case 3: emu_res_phase<KIND, 3>(E, phase, it, nsteps); break;
-            default: emu_res_phase<KIND, 4>(E, phase, it, nsteps);
+            case 1: ap ? emu_res_phase<KIND, 1, true>(E, phase, it, nsteps) : emu_res_phase<KIND, 1, false>(E, phase, it, nsteps); break;
+            case 2: ap ? emu_res_phase<KIND, 2, true>(E, phase, it, nsteps) : emu_res_phase<KIND, 2, false>(E, phase, it, nsteps); break;
+            case 3: ap ? emu_res_phase<KIND, 3, true>(E, phase, it, nsteps) : emu_res_phase<KIND, 3, false>(E, phase, it, nsteps); break;
+            default: ap ? emu_res_phase<KIND, 4, true>(E, phase, it, nsteps) : emu_res_phase<KIND, 4, false>(E, phase, it, nsteps);
             }
         };
         switch (E.h->M.kind) {
@@ -777,7 +793,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
-    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M)) : nullptr;
+    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M)) : nullptr;
     if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; A.ng = h->res_ng; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)

@@ -75,7 +75,7 @@ struct BRLay {
 
 // lanes per barcode of a loglambda segment: one per pair of time points.  (Any count works: the moment contributions are summed
 // by column walks over the segment's lanes, stride LPB, not by a butterfly over lane bits -- T = 6 used to idle one lane in four.)
-static inline int br_lpb(int T) { return T / 2; }
+static inline int br_lpb(int T) { return (T + 1) / 2; }
 
 // padded thread-index span of a tile: loglambda segments wave-aligned, LPB lanes per barcode, then the unit pairs
 static inline long long br_tile_span(const DevModel& M, long long NB, bool globals) {
@@ -92,12 +92,14 @@ static inline long long br_tile_span(const DevModel& M, long long NB, bool globa
 static inline bool br_eligible(const DevModel& M) {
     if (M.kind == 2 && !M.geno_sorted) return false;   // (genotype model: tiles must own whole genotypes, see br_tile_geno)
     if (M.quirk || M.Ttot > 64) return false;
-    for (int r = 0; r < M.R; ++r) if ((M.T[r] & 1) || M.T[r] > BR_MAXT) return false;
-    // loglambda at an odd flat index (pairs (b, 2k), (b, 2k+1) then straddle two Philox pairs): built for the genotype model only,
-    // whose other choice is the two-kernel step; the replicate models keep k_persist there (the run-time choice cost C3's
-    // instance 3 %).  Fitness / multienv layouts always start it at an even index.
-    if (M.kind != 2 && ((M.blk_lo[BK_L] & 1) || (M.off_l[0] & 1))) return false;
+    for (int r = 0; r < M.R; ++r) if (M.T[r] < 2 || M.T[r] > BR_MAXT) return false;
     return true;
+}
+// pairs (b, 2k), (b, 2k+1) of this shape are not all pairs (2q, 2q+1) of the flat index: the AP instances
+static inline bool br_any_parity(const DevModel& M) {
+    if (M.blk_lo[BK_L] & 1) return true;
+    for (int r = 0; r < M.R; ++r) if ((M.T[r] & 1) || (M.off_l[r] & 1)) return true;
+    return false;
 }
 
 static inline
@@ -183,16 +185,18 @@ struct BRSt {
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
 
-// Pair accesses.  In the fitness / multienv layouts an even number of latents precedes the loglambda block (two blocks of T - 1,
-// two of n_bc E), so a pair always sits at an even flat index; in the genotype layout (theta: n_geno, then 3 n_bc) it may sit at
-// an odd one -- then two 8-byte accesses, and two Philox pairs' halves for its normals (br_draw_call).
-template <int KIND> BB_DEV bool br_pair_aligned(long long i0) { return KIND != 2 || !(i0 & 1); }
-template <int KIND> BB_DEV bb_d2 br_load_pair(const double* base, long long i0, bool a0, bool a1) {
-    if (a0 && a1 && br_pair_aligned<KIND>(i0)) return *(const bb_d2*)(base + i0);
+// Pair accesses.  A loglambda pair (b, 2k), (b, 2k+1) normally sits at an even flat index: one Philox pair, 16-byte accesses.  It
+// does not where an odd number of latents precedes the loglambda block (genotype layout: n_geno + 3 n_bc; replicate layouts with R
+// even and n_bc odd) or the number of time points is odd (a barcode's row then starts at alternating parity, and its last lane
+// owns a single latent).  Those shapes run the AP ("any parity") instances: parity checked per pair -- two 8-byte accesses and two
+// Philox pairs' halves for the normals (br_draw_call) where it is odd.  The even shapes' instances carry none of that.
+template <bool AP> BB_DEV bool br_pair_aligned(long long i0) { return !AP || !(i0 & 1); }
+template <bool AP> BB_DEV bb_d2 br_load_pair(const double* base, long long i0, bool a0, bool a1) {
+    if (a0 && a1 && br_pair_aligned<AP>(i0)) return *(const bb_d2*)(base + i0);
     return bb_d2{a0 ? base[i0] : 0.0, a1 ? base[i0 + 1] : 0.0};
 }
-template <int KIND> BB_DEV void br_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v) {
-    if (a0 && a1 && br_pair_aligned<KIND>(i0)) { *(bb_d2*)(base + i0) = v; return; }
+template <bool AP> BB_DEV void br_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v) {
+    if (a0 && a1 && br_pair_aligned<AP>(i0)) { *(bb_d2*)(base + i0) = v; return; }
     if (a0) base[i0] = v.x;
     if (a1) base[i0 + 1] = v.y;
 }
@@ -281,7 +285,7 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
 }
 
 // ---- prologue: segment table, row map, per-thread metadata, state into registers --------------------------------
-template <int KIND, int P>
+template <int KIND, int P, bool AP = false>
 BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, BRSt<P>* stv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
@@ -335,7 +339,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                     if (2 * kk < s.T) {
                         const int t0 = 2 * kk;
                         i0 = s.lo + (long long)bl * s.T + t0;
-                        meta |= BRM_A0 | BRM_A1 | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);
+                        meta |= BRM_A0 | (t0 + 1 < s.T ? BRM_A1 : 0) | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);   // (odd T: the last lane owns one latent)
                         st.zoff[k] = s.ldsoff + bl * (s.T + 1) + t0;
                         st.pt[k] = M.tcum[s.r] + t0;
                         if (bl >= t.nshift) {
@@ -354,7 +358,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
                         }
                         const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
                         st.cnt[k][0] = M.counts[cb];
-                        st.cnt[k][1] = M.counts[cb + 1];
+                        st.cnt[k][1] = t0 + 1 < s.T ? M.counts[cb + 1] : 0u;
                     }
                 } else {
                     const int q = p - s.tbeg;
@@ -394,10 +398,10 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.i0[k] = i0;
             st.meta[k] = meta;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            st.mu[k] = br_load_pair<KIND>(S.mu, i0, a0, a1);
-            st.om[k] = br_load_pair<KIND>(S.om, i0, a0, a1);
-            st.am[k] = br_load_pair<KIND>(S.acc_mu, i0, a0, a1);
-            st.ao[k] = br_load_pair<KIND>(S.acc_om, i0, a0, a1);
+            st.mu[k] = br_load_pair<AP>(S.mu, i0, a0, a1);
+            st.om[k] = br_load_pair<AP>(S.om, i0, a0, a1);
+            st.am[k] = br_load_pair<AP>(S.acc_mu, i0, a0, a1);
+            st.ao[k] = br_load_pair<AP>(S.acc_om, i0, a0, a1);
             st.lo[k] = bb_load_lo(S, i0, a0, a1);
             st.a[k] = st.h[k] = st.z[k] = st.lam[k] = st.gp[k] = bb_d2{0.0, 0.0};
         }
@@ -435,7 +439,7 @@ void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsign
     }
 }
 
-template <int KIND, int P>
+template <int KIND, int P, bool AP = false>
 BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
     bb_d2* eps = (bb_d2*)(cx.lds + Y.eps);
     BB_PASS(cx, tid) {
@@ -443,7 +447,7 @@ BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* 
         BRIdx<P> ix;
 #pragma unroll
         for (int k = 0; k < P; ++k) { ix.i0[k] = st.i0[k]; ix.meta[k] = st.meta[k]; }
-        br_draw_call<P, (KIND == 2)>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
+        br_draw_call<P, AP>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
     }
 }
 
@@ -729,7 +733,7 @@ BB_DEV void br_pair_diffs(const double* lds, const BRLay& Y, const BRSt<P>& st, 
 // (Only where the pair state leaves room: one pair slot per thread, fitness / multienv kinds -- C2 15.4 -> 15.1 us per step; with
 //  three slots the two extra registers per slot spill, C3 22.7 -> 24.6 us.)
 template <int KIND, int P> BB_DEV constexpr bool br_has_pre() { return P == 1 && KIND <= 1; }
-template <int KIND, int P>
+template <int KIND, int P, bool AP = false>
 BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
     if (!br_has_pre<KIND, P>()) return;
     const double* lds = cx.lds;
@@ -741,12 +745,12 @@ BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
             if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
             const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT;
             double pm0, iv0, pm1, iv1, z0, z1, ap, am, an, wp, wm, wn;
-            br_pair_prior<KIND>(lds, Y, st, k, true, true, &pm0, &iv0, &pm1, &iv1);
+            br_pair_prior<KIND>(lds, Y, st, k, true, AP ? (st.meta[k] & BRM_A1) != 0 : true, &pm0, &iv0, &pm1, &iv1);
             br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);
             double A0 = ((double)st.cnt[k][0] - st.lam[k].x) - (z0 - pm0) * iv0;
             double A1 = ((double)st.cnt[k][1] - st.lam[k].y) - (z1 - pm1) * iv1;
             if (meta & BRM_MUT) {
-                const double ma = wm * am;
+                const double ma = (AP && !(meta & BRM_A1)) ? 0.0 : wm * am;        // (odd T: the last lane's single latent has no difference after it)
                 A0 += ma - (hp ? wp * ap : 0.0);
                 A1 += (hn ? wn * an : 0.0) - ma;
             }
@@ -754,7 +758,7 @@ BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
         }
     }
 }
-template <int KIND, int P>
+template <int KIND, int P, bool AP = false>
 BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, int buf, double* g0, double* g1) {
     const BBLds& L = Y.L;
     const int meta = st.meta[k], pt = st.pt[k];
@@ -762,10 +766,10 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
     const double cp = hp ? lds[L.cc + pt - 1] : 0.0, cm = lds[L.cc + pt], cn = hn ? lds[L.cc + pt + 1] : 0.0;
     if (!br_has_pre<KIND, P>()) {    // everything here, after the totals
         double pm0, iv0, pm1, iv1, z0, z1, ap, am, an, wp, wm, wn;
-        br_pair_prior<KIND>(lds, Y, st, k, true, true, &pm0, &iv0, &pm1, &iv1);
+        br_pair_prior<KIND>(lds, Y, st, k, true, AP ? (st.meta[k] & BRM_A1) != 0 : true, &pm0, &iv0, &pm1, &iv1);
         br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);
         if (!(meta & BRM_MUT)) { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
-        const double rp_ = hp ? wp * (ap - cp) : 0.0, rm_ = wm * (am - cm), rn_ = hn ? wn * (an - cn) : 0.0;
+        const double rp_ = hp ? wp * (ap - cp) : 0.0, rm_ = (AP && !(meta & BRM_A1)) ? 0.0 : wm * (am - cm), rn_ = hn ? wn * (an - cn) : 0.0;
         const double l0 = st.lam[k].x, l1 = st.lam[k].y;
         *g0 = ((double)st.cnt[k][0] - l0) + l0 * lds[Y.iG + pt] + rm_ - rp_ - (z0 - pm0) * iv0;
         *g1 = ((double)st.cnt[k][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn_ - rm_ - (z1 - pm1) * iv1;
@@ -784,7 +788,7 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
         double z0, z1, ap, am, an, wp, wm, wn;
         br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);
         rp = hp ? lds[L.wbar + pt - 1] * (ap - cp) : 0.0;
-        rm = lds[L.wbar + pt] * (am - cm);
+        rm = (AP && !(meta & BRM_A1)) ? 0.0 : lds[L.wbar + pt] * (am - cm);
         rn = hn ? lds[L.wbar + pt + 1] * (an - cn) : 0.0;
     }
     *g0 = fma(st.lam[k].x, lds[Y.iG + pt], st.gp[k].x) + (rm - rp);
@@ -794,7 +798,7 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
 // TT > 0: the number of time points is a compile-time constant -- the unit threads then fetch their barcodes' whole rows at once
 // (with the row walk as a runtime loop, one LDS round trip per time step, the unit waves' G pass took 13 k cycles against 4 k
 // for the loglambda waves and the whole tile waited for them).
-template <int KIND, int P, int TT = 0>
+template <int KIND, int P, int TT = 0, bool AP = false>
 BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                       unsigned long long step, int buf, int NBs) {
     double* lds = cx.lds;
@@ -828,7 +832,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             if (kind != SK_L) br_pair_prior<KIND>(lds, Y, st, k, a0, a1, &pm0, &iv0, &pm1, &iv1);
             double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
             if (kind == SK_L) {
-                br_l_grad<KIND>(lds, Y, st, k, buf, &g0, &g1);
+                br_l_grad<KIND, P, AP>(lds, Y, st, k, buf, &g0, &g1);
             } else if (KIND == 2 && kind == SK_TH_R) {
                 const double* stg = lds + buf * Y.SU;
 #pragma unroll
@@ -929,7 +933,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
                 BR_SCHED_FENCE();
             }
-            if (hs_m) { br_store_pair<KIND>(hs_m, st.i0[k], a0, a1, nhm); br_store_pair<KIND>(hs_o, st.i0[k], a0, a1, nho); }
+            if (hs_m) { br_store_pair<AP>(hs_m, st.i0[k], a0, a1, nhm); br_store_pair<AP>(hs_o, st.i0[k], a0, a1, nho); }
         }
     }
     }
@@ -938,7 +942,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
 }
 
 // ---- epilogue: state back to memory, step counter, status words ----------------------------------------------------------
-template <int KIND, int P>
+template <int KIND, int P, bool AP = false>
 BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned long long step_end, bool timed_out) {
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
@@ -948,10 +952,10 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
             const int meta = st.meta[k];
             if (!(meta & BRM_VALID)) continue;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            br_store_pair<KIND>(S.mu, st.i0[k], a0, a1, st.mu[k]);
-            br_store_pair<KIND>(S.om, st.i0[k], a0, a1, st.om[k]);
-            br_store_pair<KIND>(S.acc_mu, st.i0[k], a0, a1, st.am[k]);
-            br_store_pair<KIND>(S.acc_om, st.i0[k], a0, a1, st.ao[k]);
+            br_store_pair<AP>(S.mu, st.i0[k], a0, a1, st.mu[k]);
+            br_store_pair<AP>(S.om, st.i0[k], a0, a1, st.om[k]);
+            br_store_pair<AP>(S.acc_mu, st.i0[k], a0, a1, st.am[k]);
+            br_store_pair<AP>(S.acc_om, st.i0[k], a0, a1, st.ao[k]);
             bb_store_lo(S, st.i0[k], a0, a1, st.lo[k]);
             const double chk = (a0 ? st.mu[k].x + st.om[k].x : 0.0) + (a1 ? st.mu[k].y + st.om[k].y : 0.0);
             bad = bad || !(chk - chk == 0.0);
@@ -964,13 +968,13 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 }
 
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
-template <int KIND, int P>
+template <int KIND, int P, bool AP = false>
 BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
     // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
     br_prefetch_slot<P>(cx, M, S, A, Y, stv, step);
-    br_grad_pre<KIND, P>(cx, Y, stv, (int)(step & 1));          // what of this step's gradient needs no totals
-    br_draw_ahead<KIND, P>(cx, A, Y, stv, step + 1);             // the next step's normals, in the shadow of the rows' flight
+    br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(step & 1));          // what of this step's gradient needs no totals
+    br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, step + 1);         // the next step's normals, in the shadow of the rows' flight
 }
 template <bool XG>
 BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, unsigned long long step, int* ok_slot) {
@@ -988,7 +992,7 @@ BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, con
 }
 
 #ifndef BB_EMU
-template <int KIND, int P, int NT, bool XG = false, int TT = 0>
+template <int KIND, int P, int NT, bool XG = false, int TT = 0, bool AP = false>
 __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, const BRLay* __restrict__ Yp,
                                             RunArgs A, int NB, int nsteps) {
     const DevModel& M = *Mp;
@@ -1001,12 +1005,12 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
     const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
     const unsigned long long step0 = c0 > c1 ? c0 : c1;
     BB_STAMP_RT(cx, S, 2);
-    br_prologue<KIND, P>(cx, M, S, A, Y, NB, &st);
+    br_prologue<KIND, P, AP>(cx, M, S, A, Y, NB, &st);
     BB_STAMP_RT(cx, S, 3);
     const bool dead = *ok_slot == 0;
     int done = 0;
     if (!dead) {
-        br_draw_ahead<KIND, P>(cx, A, Y, &st, step0);
+        br_draw_ahead<KIND, P, AP>(cx, A, Y, &st, step0);
         BB_STAMP_RT(cx, S, 4);
         for (; done < nsteps; ++done) {
             const unsigned long long step = step0 + (unsigned long long)done;
@@ -1022,15 +1026,15 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
             }
             br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
             br_moments<KIND, P>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<KIND, P>(cx, M, S, A, Y, &st, step);
+            br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, step);
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
             if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
-            br_update<KIND, P, TT>(cx, M, S, A, Y, &st, step, buf, NB);
+            br_update<KIND, P, TT, AP>(cx, M, S, A, Y, &st, step, buf, NB);
         }
     }
     BB_STAMP_RT(cx, S, 5);
-    br_epilogue<KIND, P>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
+    br_epilogue<KIND, P, AP>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
     BB_STAMP_RT(cx, S, 6);
 }
 #endif

@@ -30,6 +30,7 @@ SYNTH = {
     "genotype": ("genotype", dict(B=800, T=6, n_geno=17, n_neutral=256)),
     "genotype_runs": ("genotype", dict(B=800, T=6, n_geno=40, n_neutral=256, geno_runs=True)),   # mutants grouped by genotype: k_res owns whole genotypes per tile
     "genotype_T8": ("genotype", dict(B=1000, T=8, n_geno=60, n_neutral=30, geno_runs=True)),
+    "genotype_T5": ("genotype", dict(B=600, T=5, n_geno=30, n_neutral=50, geno_runs=True)),          # odd number of time points: k_res any-parity instances
     "genotype_odd": ("genotype", dict(B=800, T=6, n_geno=41, n_neutral=256, geno_runs=True)),      # loglambda starts at an ODD flat index: a k_res pair is two Philox pairs' halves
     "replicate_odd": ("replicate", dict(B=302, T=[6, 4], n_rep=2, n_neutral=1)),                  # ... likewise (301 mutants, two replicates): k_persist
     "replicate_ragged": ("replicate", dict(B=530, T=[5, 7, 4], n_rep=3, n_neutral=20)),

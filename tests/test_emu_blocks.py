@@ -61,8 +61,13 @@ def test_launch_geometries(emu_lib, monkeypatch, nb, nthr):
 
 @pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d", "multienv_replicate",
                                   "multienv_replicate_3d"])
-def test_persistent_equals_two_kernel(emu_lib, name):
+def test_persistent_equals_two_kernel(emu_lib, monkeypatch, name):
+    """Odd numbers of time points / an odd loglambda offset.  By default these shapes run k_persist (measured faster there); k_res
+    has any-parity instances for them -- a barcode's last lane owns a single latent, pairs take their normals from two Philox
+    pairs where their flat index is odd -- used where k_persist cannot run (genotype model, oversize tiles) and forced here."""
     c.case_persistent_equals_two_kernel(emu_lib, name)
+    monkeypatch.setenv("BB_TUNE_AP", "1")
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
 @pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8",
@@ -124,7 +129,7 @@ def test_owner_computes_launch_long_moment_row(emu_lib, monkeypatch, nb, nthr, k
     c.case_persistent_equals_two_kernel(emu_lib, "replicate_R4", expect_kernel=kernel)
 
 
-@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
+@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8", "genotype_T5"])
 def test_owner_computes_launch_genotype(emu_lib, name):
     """Genotype model under k_res: mutants grouped by genotype, tiles cut at genotype boundaries own their genotypes' theta
     (sample, stage, d/dtheta_g = sum over the genotype's mutants inside the tile, update) -- against the two-kernel step with
@@ -132,13 +137,13 @@ def test_owner_computes_launch_genotype(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
-@pytest.mark.parametrize("name", ["genotype_odd"])
+@pytest.mark.parametrize("name", ["genotype_odd", "replicate_odd"])
 def test_owner_computes_launch_odd_loglambda_offset(emu_lib, monkeypatch, name):
     """An odd number of latents in front of the loglambda block: a pair (b, 2k), (b, 2k+1) then straddles two Philox pairs
-    (2q - 1, 2q) -- two draws per thread, 8-byte state accesses; same draws, same arithmetic as everywhere else.  Also sharded.
-    (Built for the genotype model, whose other choice is the two-kernel step; replicate shapes like this keep k_persist.)"""
+    (2q - 1, 2q) -- two draws per thread, 8-byte state accesses; same draws, same arithmetic as everywhere else.  Also sharded."""
     sp = c.synth(name, seed=6)
     assert sp.offsets()["loglambda"][0] % 2 == 1
+    monkeypatch.setenv("BB_TUNE_AP", "1")        # (the genotype model takes the any-parity instances by itself)
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
     monkeypatch.setenv("BB_TUNE_NB", "24" if name == "genotype_odd" else "16")      # (>= 8 tiles per rank)
     monkeypatch.setenv("BB_TUNE_NTHR", "128")
@@ -165,6 +170,7 @@ def test_owner_computes_launch_genotype_sharded(emu_lib, monkeypatch, world):
     monkeypatch.setenv("BB_TUNE_NTHR", "128")
     c.case_p2p_resident(emu_lib, "genotype_runs", world)
     c.case_p2p_resident(emu_lib, "genotype_T8", world)
+    c.case_p2p_resident(emu_lib, "genotype_T5", world)
     c.case_multi_device_handle(emu_lib, "genotype_runs", n=world)
 
 
@@ -203,6 +209,18 @@ def test_running_window_stays_near_the_exact_window(emu_lib, mode):
             outs[resum] = e.get_params()
     for resum in (0, 100000):
         assert np.abs(outs[resum][0] - outs[1][0]).max() < 1e-9 and np.abs(outs[resum][1] - outs[1][1]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged", "multienv_replicate_3d", "fitness_T6"])
+def test_first_generation_resident_launch(emu_lib, monkeypatch, name):
+    """k_persist (LDS-staged passes, bb_persist.h) stays the fallback where k_res does not apply -- the ragged-method pairing,
+    moment rows longer than a tile has threads, more than 16 time points; BB_NO_RES=1 selects it everywhere."""
+    monkeypatch.setenv("BB_NO_RES", "1")
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=1)
+    if name in ("fitness_multi_tile", "replicate_ragged"):
+        monkeypatch.setenv("BB_TUNE_NB", "16")
+        monkeypatch.setenv("BB_TUNE_NTHR", "512")
+        c.case_p2p_resident(emu_lib, name, 2)
 
 
 def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):

@@ -113,8 +113,21 @@ def test_rccl_path_single_rank(hip_lib, monkeypatch):
 
 @pytest.mark.parametrize("name", ["fitness_multi_tile", "fitness_T2", "multienv", "replicate_ragged", "replicate_3d", "multienv_replicate",
                                   "multienv_replicate_3d"])
-def test_persistent_equals_two_kernel(hip_lib, name):
+def test_persistent_equals_two_kernel(hip_lib, monkeypatch, name):
+    """Odd numbers of time points / an odd loglambda offset.  By default these shapes run k_persist (measured faster there); k_res
+    has any-parity instances for them -- a barcode's last lane owns a single latent, pairs take their normals from two Philox
+    pairs where their flat index is odd -- used where k_persist cannot run (genotype model, oversize tiles) and forced here."""
     c.case_persistent_equals_two_kernel(hip_lib, name)
+    monkeypatch.setenv("BB_TUNE_AP", "1")
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
+
+
+@pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged", "multienv_replicate_3d", "fitness_T6"])
+def test_first_generation_resident_launch(hip_lib, monkeypatch, name):
+    """k_persist stays the fallback where k_res does not apply (ragged-method pairing, moment rows longer than a tile has
+    threads, more than 16 time points); BB_NO_RES=1 selects it everywhere."""
+    monkeypatch.setenv("BB_NO_RES", "1")
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=1)
 
 
 def test_persistent_two_pairs_per_thread(hip_lib, monkeypatch):
@@ -231,17 +244,18 @@ def test_owner_computes_launch_exchange_shapes(hip_lib, monkeypatch, nb, nthr, n
     c.case_persistent_equals_two_kernel(hip_lib, "multienv_T8", expect_kernel=2)
 
 
-@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8"])
+@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8", "genotype_T5"])
 def test_owner_computes_launch_genotype(hip_lib, name):
     """Genotype model under k_res (mutants grouped by genotype, tiles own whole genotypes and their theta): same arithmetic as
     the two-kernel step with its grid-wide per-genotype sums, and as the literal oracle's optimiser trajectory."""
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
 
 
-@pytest.mark.parametrize("name", ["genotype_odd"])
+@pytest.mark.parametrize("name", ["genotype_odd", "replicate_odd"])
 def test_owner_computes_launch_odd_loglambda_offset(hip_lib, monkeypatch, name):
     """loglambda starting at an odd flat index: a k_res pair takes its normals from two Philox pairs and moves as 8-byte
     accesses (the LDS-DMA window-slot prefetch from an 8-byte-aligned address)."""
+    monkeypatch.setenv("BB_TUNE_AP", "1")        # (the genotype model takes the any-parity instances by itself)
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
     monkeypatch.setenv("BB_TUNE_NB", "24" if name == "genotype_odd" else "16")
     monkeypatch.setenv("BB_TUNE_NTHR", "128")
