@@ -21,12 +21,13 @@
 // Three workgroup barriers per step (+ the leaders' two).  LDS tables that a later phase of the SAME step still reads
 // while fast waves already write the next step's values (z, unit stages) are double-buffered by step parity.
 //
-// Lane mapping: every loglambda segment (one per replicate) starts at a wave boundary; LPB = T/2 lanes per barcode,
+// Lane mapping: every loglambda segment (one per replicate) starts at a wave boundary; LPB = ceil(T/2) lanes per barcode,
 // lane = bl * LPB + k owns (b, 2k), (b, 2k+1).  Their moment contributions go to LDS transposed (one column entry per lane)
-// and are summed by column walks of stride LPB.  Unit pairs follow, flat.  Needs: every T_r even and <= 16 (a barcode's time
-// points then split into whole pairs), not the ragged-method quirk; other shapes keep k_persist.  A loglambda pair is (b, 2k),
-// (b, 2k+1); where the block starts at an odd flat index (genotype model only, br_eligible) the two latents belong to two
-// different Philox pairs (two draws) and move as 8-byte accesses.
+// and are summed by column walks of stride LPB.  Unit pairs follow, flat.  Needs: 2 <= T_r <= 16, not the ragged-method quirk;
+// other shapes keep k_persist.  A loglambda pair is (b, 2k), (b, 2k+1): where T is even and an even number of latents precedes
+// the block, that is a pair (2q, 2q+1) of the flat index (one Philox pair, 16-byte accesses) and the plain instances run; the
+// AP ("any parity") instances take odd T (LPB = (T+1)/2, a barcode's last lane owns a single latent) and odd offsets, with the
+// parity of every pair a run-time property (two draws, 8-byte accesses where odd).
 //
 // Written, like bb_persist.h, as passes over an explicit per-thread state so that the host emulation (tests) runs the
 // same source; the wave-level operations (a DPP row sum, the LDS-DMA prefetch) have emulation twins that add / move the same
