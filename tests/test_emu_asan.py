@@ -32,6 +32,9 @@ os.environ["BB_TUNE_NB"] = "40"; os.environ["BB_TUNE_NTHR"] = "128"        # two
 c.case_persistent_equals_two_kernel(lib, "fitness_T4", expect_kernel=2)
 del os.environ["BB_TUNE_NB"]; del os.environ["BB_TUNE_NTHR"]
 c.case_hier_fitness(lib, "genotype")
+c.case_synth_grad(lib, "replicate_ragged")                                # the two-kernel block programs
+c.case_trajectory_exact(lib, "genotype", "TruncatedADAGrad", 2)
+c.case_sharded_split_phase(lib, "multienv")
 print("ASAN-CLEAN")
 '''
 

@@ -283,7 +283,7 @@ def test_c2_shards_are_eligible_for_the_resident_launch(emu_lib, world):
     from barbay_jl_amd import synth
     import barbay_jl_amd as bb
     wl = synth.fitness_normal(50_000, 8, 42)
-    es = [bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, rank=r, world_size=world, _lib=emu_lib) for r in range(world)]
+    es = [bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, rank=r, world_size=world, window=2, _lib=emu_lib) for r in range(world)]   # (window: geometry does not depend on it; 100 slots are 0.8 GB per handle)
     try:
         handles = [e.p2p_export() for e in es]
         for e in es:
