@@ -101,8 +101,8 @@ typedef struct bb_advi_opts {
     int32_t resum_every;      /* TruncatedADAGrad: 1 = re-add the whole window every step
                                  (same arithmetic as the reference's sum(g2)); k > 1 =
                                  running sum, exact re-add every k steps; 0 (default) =
-                                 at every multiple of `window` up to 10 windows, then at
-                                 every multiple of 10 windows                            */
+                                 running sum, never re-added: it is a compensated
+                                 (two-sum) accumulator, 1e-14 from the exact window sum   */
     double pre;               /* DecayedADAGrad, default 1.0                             */
     double post;              /* DecayedADAGrad, default 0.9                             */
     uint64_t seed;            /* Philox key (DESIGN.md "RNG stream")                     */
