@@ -16,10 +16,14 @@ from barbay_jl_amd import synth  # noqa: E402
 from oracle import advi, port  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
-wl = synth.fitness_normal(50_000, 8, 42)
+# CFG = C2 (default) | C3 | C4 | C5rank: the same check on the other BASELINE shapes (C5 as one of its eight ranks sees it)
+wl = {"C2": lambda: synth.fitness_normal(50_000, 8, 42), "C3": lambda: synth.replicate_fitness_normal(20_000, 6, 3, 43),
+      "C4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
+      "C5rank": lambda: synth.genotype_fitness_normal(25_000, 8, 625, 45)}[os.environ.get("CFG", "C2")]()
 sp = port.spec_from_workload(wl)
 t0 = time.perf_counter()
-with bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42) as e:
+with bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=42) as e:
+    resident = e.stats()["resident_kernel"]
     mu0, om0 = e.get_params()
     e.run(iters)
     m_g, s_g = e.posterior()
@@ -38,13 +42,13 @@ s_c = advi.softplus(om)
 mu2, om2, _, _ = p.run(m0, o0, iters, seed=43, nthreads=port.usable_cores())
 s_c2 = advi.softplus(om2)
 off = sp.offsets()
-lo, hi = off["s_bc"]
-truth = np.asarray(wl.truth["s"]) if getattr(wl, "truth", None) else None
+truth = np.asarray(wl.truth["s"]) if getattr(wl, "truth", None) and "s" in wl.truth and "s_bc" in off else None
+lo, hi = off["s_bc"] if truth is not None else (0, 0)
 d_impl, d_seed = np.abs(m_g - mu) / s_c, np.abs(mu2 - mu) / s_c
 l_impl, l_seed = np.abs(np.log(s_g) - np.log(s_c)), np.abs(np.log(s_c2) - np.log(s_c))
 q = lambda x: [float(np.quantile(x, v)) for v in (0.5, 0.99, 1.0)]
 out = {
-    "workload": wl.name, "iterations": iters, "gpu_seconds": round(t_gpu, 2), "cpu_port_seconds": round(t_cpu, 2),
+    "workload": wl.name, "resident_kernel": {0: "two kernels", 1: "k_persist", 2: "k_res"}[resident], "iterations": iters, "gpu_seconds": round(t_gpu, 2), "cpu_port_seconds": round(t_cpu, 2),
     "cpu_threads": port.usable_cores(),
     "abs_mean_diff_over_cpu_std [median, p99, max]": {"gpu_vs_cpu_same_stream": q(d_impl), "cpu_seed42_vs_cpu_seed43": q(d_seed)},
     "abs_log_std_diff [median, p99, max]": {"gpu_vs_cpu_same_stream": q(l_impl), "cpu_seed42_vs_cpu_seed43": q(l_seed)},
