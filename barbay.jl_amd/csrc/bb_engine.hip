@@ -1486,6 +1486,7 @@ static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
         o.device = opts->device_ids ? opts->device_ids[i] : i;
         o.rank = i;
         o.world_size = n;
+        o.launch_mode = opts->launch_mode == 1 ? 1 : 0;      // (a shard alone cannot run resident before its inbox is wired: mode 2 is enforced below, on the group)
         bb_handle* sh = nullptr;
         rc = bb_create(md, &o, &sh);
         if (!rc) { sh->in_group = true; g->shards.push_back(sh); }
@@ -1529,7 +1530,11 @@ static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
     if (ok) for (int i = 0; i < n && ok; ++i) ok = bb_p2p_enable(g->shards[i], 1) == BB_OK;
     if (!ok) for (bb_handle* sh : g->shards) if (sh->p2p_ready) (void)bb_p2p_enable(sh, 0);
     g->group_resident = ok;
-    if (!ok && opts->launch_mode == 2) { group_destroy(g); return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2: the shards cannot run resident launches with peer-mapped inboxes: %s", g_err); }
+    if (!ok && opts->launch_mode == 2) {
+        const std::string why(g_err);                 // (bb_fail formats INTO g_err: the message must not be its own argument)
+        group_destroy(g);
+        return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2: the shards cannot run resident launches with peer-mapped inboxes: %s", why.c_str());
+    }
     *out = g;
     return BB_OK;
 }

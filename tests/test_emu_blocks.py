@@ -276,14 +276,18 @@ def test_sharded_resident_launch_chunked_inbox(emu_lib, monkeypatch):
     c.case_p2p_resident(emu_lib, "fitness_multi_tile", 3)
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_c2_shards_are_eligible_for_the_resident_launch(emu_lib, world):
-    """The headline workload split over 2 / 4 / 8 ranks: every rank's geometry must leave one pair per thread and >= 8 tiles,
-    otherwise bench.py --gpus N silently stays on the RCCL step (W = 4 used to: 257 pairs on 256 threads)."""
+@pytest.mark.parametrize("cfg,world", [("C2", 2), ("C2", 4), ("C2", 8), ("C4", 4), ("C5", 8)])
+def test_baseline_shards_run_the_owner_computes_launch(emu_lib, cfg, world):
+    """Every shard shape BASELINE.json names -- the headline workload over 2 / 4 / 8 ranks, C4 (multienv) over 4, C5 (genotype)
+    over 8 -- must select k_res with its cross-GPU exchange (resident_kernel == 2) on every rank, with >= 8 tiles: otherwise
+    bench.py --gpus N silently stays on the RCCL step (C2 / 4 used to: 257 pairs on 256 threads) or on round 1's kernel."""
     from barbay_jl_amd import synth
     import barbay_jl_amd as bb
-    wl = synth.fitness_normal(50_000, 8, 42)
-    es = [bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42, rank=r, world_size=world, window=2, _lib=emu_lib) for r in range(world)]   # (window: geometry does not depend on it; 100 slots are 0.8 GB per handle)
+    wl = {"C2": lambda: synth.fitness_normal(50_000, 8, 42),
+          "C4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
+          "C5": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45)}[cfg]()
+    es = [bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=42, rank=r, world_size=world,
+                    window=2, _lib=emu_lib) for r in range(world)]   # (window: geometry does not depend on it; 100 slots are 0.8 GB per handle)
     try:
         handles = [e.p2p_export() for e in es]
         for e in es:
@@ -291,7 +295,9 @@ def test_c2_shards_are_eligible_for_the_resident_launch(emu_lib, world):
         assert all(e.p2p_selftest() for e in es)
         assert all(e.p2p_enable(True) for e in es)
         st = [e.stats() for e in es]
-        assert all(s["persistent_pairs"] == 1 and s["n_blocks"] >= 8 for s in st), st
+        assert all(s["resident_kernel"] == 2 and s["n_blocks"] >= 8 for s in st), st
+        if cfg != "C5":
+            assert all(s["persistent_pairs"] == 1 for s in st), st
     finally:
         for e in es:
             e.close()
@@ -337,6 +343,18 @@ def test_multi_device_handle(emu_lib, monkeypatch, name, n):
     monkeypatch.setenv("BB_TUNE_NB", "16")
     monkeypatch.setenv("BB_TUNE_NTHR", "256")
     c.case_multi_device_handle(emu_lib, name, n)
+
+
+def test_multi_device_handle_launch_mode_2(emu_lib, monkeypatch):
+    """launch_mode = 2 on a multi-device handle: the shards are created before their inboxes are wired (a shard alone cannot run
+    resident then) and the mode is enforced on the group afterwards; where the group cannot run resident it is an error."""
+    import barbay_jl_amd as bb
+    from conftest import make_engine
+    monkeypatch.setenv("BB_TUNE_NB", "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "256")
+    c.case_multi_device_handle(emu_lib, "fitness_T6", 2, launch_mode=2)
+    with pytest.raises(bb.BarBayHipError, match="launch_mode = 2"):
+        make_engine(c.synth("genotype"), emu_lib, device_ids=[0, 0], launch_mode=2)
 
 
 def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeypatch):

@@ -216,11 +216,49 @@ def test_runs_are_bit_reproducible(hip_lib, mode):
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
 
 
-@pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8"])
+@pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8",
+                                  "replicate_T6", "replicate_R3", "multienv_replicate_T6", "multienv_replicate_R3"])
 def test_owner_computes_launch_equals_two_kernel(hip_lib, name):
     """Even T: launch_mode 2 is k_res (bb_resident.h, the owner of a latent computes); same arithmetic as the two-kernel
     step and as the literal oracle's optimiser trajectory."""
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
+
+
+@pytest.mark.parametrize("name", ["replicate_T6", "replicate_R3", "multienv_replicate_T6", "multienv_replicate_R3"])
+@pytest.mark.parametrize("opt", ["TruncatedADAGrad", "DecayedADAGrad"])
+def test_owner_computes_launch_hierarchical_trajectory(hip_lib, name, opt):
+    """The plain (even T, even offset) k_res instances of the replicate kinds against the literal oracle's optimiser loop."""
+    from conftest import make_engine
+    sp = c.synth(name, seed=2)
+    e, a, b, _ = c._trajectory(hip_lib, sp, 12, 1, opt, window=5, resum_every=1, launch_mode=2)
+    k = e.stats()["resident_kernel"]
+    e.close()
+    assert k == 2 and a < 1e-10 and b < 1e-10, (k, a, b)
+
+
+@pytest.mark.parametrize("cfg", ["C3_replicate", "C4_multienv", "multienv_replicate_even"])
+def test_baseline_kernel_instance_against_the_oracle_loop(hip_lib, monkeypatch, cfg):
+    """The kernel instance a BASELINE workload runs at full size -- C3: k_res<replicate, 3 pair slots, 512 threads, T = 6>, C4:
+    k_res<multienv, 1, 1024, T = 6> -- on a 2 000-barcode cut with the full-size tile geometry (barcodes per tile, threads),
+    against the LITERAL oracle's ADVI loop (exact window), not only against the two-kernel step."""
+    from conftest import make_engine
+    from oracle import fixtures
+    if cfg == "C3_replicate":
+        sp = fixtures.synthetic("replicate", B=2000, T=6, n_rep=3, n_neutral=40, seed=43)
+        nb, nthr, pairs = 79, 512, 3           # 20 000 barcodes / 256 tiles, 65 % leaders
+    elif cfg == "C4_multienv":
+        sp = fixtures.synthetic("multienv", B=2000, T=6, n_env=4, n_neutral=40, seed=44)
+        nb, nthr, pairs = 79, 1024, 1
+    else:
+        sp = fixtures.synthetic("multienv_replicate", B=1500, T=6, n_rep=2, n_env=3, n_neutral=30, seed=46)
+        nb, nthr, pairs = 60, 512, None
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    e, a, b, _ = c._trajectory(hip_lib, sp, 10, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
+    st = e.stats()
+    e.close()
+    assert st["resident_kernel"] == 2 and st["block_threads"] == nthr and (pairs is None or st["persistent_pairs"] == pairs), st
+    assert a < 1e-10 and b < 1e-10, (a, b)
 
 
 @pytest.mark.parametrize("nb,nthr", [(100, 256), (24, 128), (150, 512), (40, 128), (9, 64), (96, 1024)])
