@@ -488,6 +488,11 @@ static bool try_resident(bb_handle* h, bool any_parity) {
         const int KK = h->M.K + 2 * h->M.nt1;
         int ng = (!h->p2p_on && h->nblk >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)) ? 16 : 8;
         if ((ev = getenv("BB_TUNE_NG")) && (atoi(ev) == 8 || (atoi(ev) == 16 && !h->p2p_on && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)))) ng = atoi(ev);
+#if BR_TG
+        // self-validating rows: a leader takes its members' rows in batches of eight loads per lane -- 32 groups of 8 on a full grid:
+        // one batch, one round trip (the tile's consume then runs on four thread groups)
+        if (ev && atoi(ev) == 32 && !h->p2p_on && h->nblk >= 64 && h->nthr >= 4 * ((KK + 63) & ~63)) ng = 32;
+#endif
         h->res_ng = ng;
     }
     const int NGh = h->res_ng;
@@ -682,7 +687,8 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             br_draw_ahead<KIND, PP, AP>(cx, A, Y, sb, (unsigned long long)h->step);
         } else if (phase == 1) {
             br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
-            br_moments<KIND, PP>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
+            if (xg || !BR_TG) br_moments<KIND, PP, false>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
+            else br_moments<KIND, PP, true>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, step);
         } else if (phase == 2) {
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);
@@ -1134,6 +1140,8 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
 #endif
     BB_TRY(dalloc(h, &S.prow, (size_t)(h->nblk + 8) * (M.K + 2 * M.nt1)));      // (+ 8: k_res's own tile map may need a few tiles more)
     BB_TRY(dalloc(h, &S.xrow, (size_t)2 * BB_NG_MAX * (M.K + 2 * M.nt1)));
+    BB_TRY(dalloc(h, &S.grow, (size_t)(h->nblk + 8 + 16 * BB_NG_MAX) * (M.K + 2 * M.nt1)));      // (+ 16 groups x 16: a leader's eight loads in flight run past its last member, bb_gran_poll8)
+    BB_TRY(dalloc(h, &S.gxrow, (size_t)2 * BB_NG_MAX * (M.K + 2 * M.nt1)));
     BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 2 * BB_NG_MAX)));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));

@@ -76,22 +76,23 @@ BB_DEV double bb_rcp(double x) {
     return r;
 }
 
-// a / b with one residual correction (<= 1 ulp).
+// a / b with one residual correction (<= 1 ulp).  The reciprocal behind it needs one Newton step only: the correction squares
+// its error (gfx950: seed 2^-24.4, one step 2.2e-15 -- tools/probe/seed_accuracy.hip).
 BB_DEV double bb_div(double a, double b) {
-    const double r = bb_rcp(b);
+    double r = BB_RCP_SEED(b);
+    r = fma(fma(-b, r, 1.0), r, r);
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
 
-// sqrt(x), x >= 0 (0 -> 0): rsq seed, coupled Newton (Goldschmidt) + final residual correction.
+// sqrt(x), x >= 0 (0 -> 0): rsq seed, ONE coupled Newton (Goldschmidt) iteration + final residual correction -- measured on
+// gfx950 (tools/probe/seed_accuracy.hip): the seed is good to 2^-24.2, the iteration squares that and the correction leaves 1.1e-16,
+// the same as with a second iteration.
 BB_DEV double bb_sqrt(double x) {
     if (!(x > 0.0)) return x == 0.0 ? 0.0 : sqrt(x);
     const double y = BB_RSQ_SEED(x);
     double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
+    const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
     return fma(fma(-g, g, x), h, g);
@@ -126,11 +127,35 @@ BB_DEV double bb_log(double x) {
 
 // softplus / sigmoid of omega sharing one exp, one reciprocal and one log:
 //   e = exp(-|w|) in (0, 1], u = 1 + e, log1p(e) = log(u) + (e - (u - 1)) / u  (exact-sum correction)
+// (exp of a non-positive argument: no upper clamp; log of u in (1, 2]: the exponent is 0 or 1 -- the same bits as bb_exp / bb_log)
+BB_DEV double bb_exp_nonpos(double x) {
+    bb_cdouble* c = bb_tab(bb_c_exp);
+    x = fmax(x, -746.0);
+    const double k = rint(x * c[12]);
+    double r = fma(-k, c[13], x);
+    r = fma(-k, c[14], r);
+    double p = bb_horner11(c[0], r, c + 1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+BB_DEV double bb_log_1to2(double u) {
+    bb_cdouble* c = bb_tab(bb_c_log);
+    const double hu = 0.5 * u;
+    const bool up = !(hu < c[14]);                      // u / 2 in [sqrt(1/2), 1]: m = u / 2, exponent 1; else m = u, exponent 0
+    const double m = up ? hu : u;
+    const double s = bb_div(m - 1.0, m + 1.0);
+    const double z = s * s;
+    double p = bb_horner11(c[0], z, c + 1);
+    const double lm = fma(2.0 * s * z, p, 2.0 * s);
+    const double ef = up ? 1.0 : 0.0;
+    return fma(ef, c[12], fma(ef, c[13], lm));
+}
 BB_DEV void bb_softplus_sigmoid_fast(double om, double* sp, double* sig) {
-    const double e = bb_exp(-fabs(om));
+    const double e = bb_exp_nonpos(-fabs(om));
     const double u = 1.0 + e;
     const double inv = bb_rcp(u);
-    const double l1p = e < 0x1.0p-54 ? e : fma(e - (u - 1.0), inv, bb_log(u));
+    const double l1p = e < 0x1.0p-54 ? e : fma(e - (u - 1.0), inv, bb_log_1to2(u));
     *sp = fmax(om, 0.0) + l1p;
     *sig = om >= 0.0 ? inv : e * inv;
 }

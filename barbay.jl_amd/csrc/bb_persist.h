@@ -310,7 +310,7 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
 // row of the previous step, which the leaders publish only after reading all member rows).  Every poll is bounded.
 typedef unsigned long long bb_u64;
 
-#define BB_NG_MAX 16       /* groups of the exchange's first hop: RunArgs.ng = 8 (the cross-GPU inbox protocol is laid out for 8) or 16 */
+#define BB_NG_MAX 32       /* groups of the exchange's first hop: RunArgs.ng = 8 (the cross-GPU inbox protocol is laid out for 8), 16, or -- self-validating rows only -- 32 */
 BB_DEV int bbp_groups(const RunArgs& A) { return A.nblk < A.ng ? A.nblk : A.ng; }
 
 // Poll *word until it equals epoch; false = gave up (timeout word set).
@@ -345,6 +345,157 @@ BB_DEV void bb_set_word(unsigned* word, unsigned v) {
 #else
     __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+}
+
+// ---- self-validating rows (k_res on one GPU, BR_TG) -------------------------------------------------------------------
+// A row entry travels as ONE 16-byte write-through store {lo32, tag, hi32, tag}: two 8-byte granules that each carry the step's
+// tag (= the ready words' epoch: base + step + 1, only ever growing).  A reader takes a value only when both tags match, so the
+// row needs no ready word: the producer neither drains its stores nor meets at a barrier nor stores a flag, and a reader's poll
+// of the row IS its read -- two round trips and two workgroup barriers less per hop than the ready-word protocol
+// (tools/probe/xchg_probe.hip: 4.2 -> 3.7 us for the bare two-hop chain on an idle chip).  8-byte granules are written and read
+// whole by the hardware (observed, as the CDNA guide's R2 form); the two halves of the 16-byte store may land apart -- hence a
+// tag in each.  The loads are inline asm (no builtin gives a 16-byte sc1 load): the compiler does not know they are
+// asynchronous, so the wait behind them takes the destination registers as operands and nothing that reads them can move up.
+struct alignas(16) bb_gran { unsigned lo, t0, hi, t1; };
+#ifndef BR_TG
+#define BR_TG 1
+#endif
+#ifndef BB_EMU
+typedef unsigned bb_v4u __attribute__((ext_vector_type(4)));
+#endif
+BB_DEV void bb_gran_st(bb_gran* p, double v, unsigned tag) {
+#ifdef BB_EMU
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    *p = bb_gran{(unsigned)b, tag, (unsigned)(b >> 32), tag};
+#else
+    bb_v4u g = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
+#endif
+}
+// The entries base[off + i * stride], i < 8: poll until those with i < n carry `tag` in both halves, then their values in order
+// (i >= n: +0.0; their loads still run -- the row buffers are allocated with the slack for it).  `base`, `stride` uniform, `off`
+// per lane: ONE address register for the eight loads in flight (scalar base + 32-bit lane offset, advanced between the loads) --
+// with eight 64-bit lane addresses beside the 32 destination registers the step loop of the 1024-thread instances spilled.  One
+// call per thread with a row entry; the lanes of a wave leave together.  false = gave up.
+BB_DEV bool bb_gran_poll8(const bb_gran* base, unsigned off, unsigned stride, int n, unsigned tag, bool active, unsigned* tmo, unsigned limit, double* out) {
+#ifdef BB_EMU
+    (void)tmo; (void)limit;
+    bool good = true;
+    for (int i = 0; i < 8; ++i) {
+        out[i] = 0.0;
+        if (!active || i >= n) continue;
+        const bb_gran g = base[off + i * stride];
+        good = good && g.t0 == tag && g.t1 == tag;
+        const unsigned long long b = (unsigned long long)g.lo | ((unsigned long long)g.hi << 32);
+        memcpy(&out[i], &b, 8);
+    }
+    return good;                          // the emulation runs the phases in order: the rows must already be there
+#else
+    bb_v4u g0, g1, g2, g3, g4, g5, g6, g7;
+    bool ok = true;
+    // (uniform by construction; the readfirstlanes tell the compiler so -- the "s" operands must be scalar registers)
+    const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(stride * 16u));
+    const unsigned long long bp = (unsigned long long)base;
+    const unsigned long long sbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bp);
+    for (unsigned spins = 0;; ++spins) {
+        unsigned vo = off * 16u;
+        asm volatile("global_load_dwordx4 %0, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %1, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %2, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %3, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %4, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %5, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %6, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
+                     "global_load_dwordx4 %7, %8, %9 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7), "+v"(vo)
+                     : "s"(sbase), "s"(sb) : "memory");
+        const bool good = ((g0.y == tag && g0.w == tag) || n < 1) && ((g1.y == tag && g1.w == tag) || n < 2) && ((g2.y == tag && g2.w == tag) || n < 3) &&
+                          ((g3.y == tag && g3.w == tag) || n < 4) && ((g4.y == tag && g4.w == tag) || n < 5) && ((g5.y == tag && g5.w == tag) || n < 6) &&
+                          ((g6.y == tag && g6.w == tag) || n < 7) && ((g7.y == tag && g7.w == tag) || n < 8);
+        if (__builtin_amdgcn_ballot_w64(active && !good) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > limit) {
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+#define BB_GV(g) __hiloint2double((int)g.z, (int)g.x)
+    out[0] = n > 0 ? BB_GV(g0) : 0.0; out[1] = n > 1 ? BB_GV(g1) : 0.0; out[2] = n > 2 ? BB_GV(g2) : 0.0; out[3] = n > 3 ? BB_GV(g3) : 0.0;
+    out[4] = n > 4 ? BB_GV(g4) : 0.0; out[5] = n > 5 ? BB_GV(g5) : 0.0; out[6] = n > 6 ? BB_GV(g6) : 0.0; out[7] = n > 7 ? BB_GV(g7) : 0.0;
+#undef BB_GV
+    return ok;
+#endif
+}
+
+// leader of group g = tile g: its members' rows (16 at most per batch of two polls), summed in member order, out as the group row
+BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int par, unsigned epoch, int* ok) {
+    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A), g = cx.block;
+    const int members = (A.nblk - g + NG - 1) / NG;
+    BB_PASS(cx, tid) {
+        if (tid < ((KK + 63) & ~63)) {             // (whole waves: the lanes of a wave poll together)
+            const bool act = tid < KK;
+            const int k = act ? tid : KK - 1;
+            double s = 0.0;
+            for (int m0 = 0; m0 < members; m0 += 8) {
+                double v[8];
+                const int n = members - m0 < 8 ? members - m0 : 8;
+                if (!bb_gran_poll8(S.grow + (long long)g * KK, (unsigned)(m0 * NG * KK + k), (unsigned)(NG * KK), n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[i];
+            }
+            if (act) bb_gran_st(S.gxrow + ((long long)par * NG + g) * KK + k, s, epoch);
+        }
+    }
+    BB_STAMP(cx, S, 18);
+}
+
+// every tile: the NG group rows, eight per thread group -- groups [8 q, 8 q + 8) by threads [q KKP, q KKP + KK), q < NG / 8 <= 4, all
+// polling at once; the partial sums of q >= 1 cross through LDS and are added in group order: ((q0 + q1) + q2) + q3
+BB_DEV void bbp_consume_tg(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par, unsigned epoch, int* ok) {
+    double* lds = cx.lds;
+    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A);
+    const int KKP = (KK + 63) & ~63, NQ = (NG + 7) >> 3;
+    double s0 = 0.0;
+    BB_PASS(cx, tid) {
+        const int q = tid / KKP, kk = tid - q * KKP;
+        if (q < NQ) {
+            const bool act = kk < KK;
+            const int k = act ? kk : KK - 1, g0 = 8 * q;
+            double v[8];
+            const int n = NG - g0 < 8 ? NG - g0 : 8;
+            if (!bb_gran_poll8(S.gxrow + (long long)par * NG * KK, (unsigned)(g0 * KK + k), (unsigned)KK, n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+            if (q > 0) { if (act) lds[L.red + (q - 1) * KKP + kk] = s; }
+            else {
+#ifdef BB_EMU
+                if (act) lds[L.red + 3 * KKP + kk] = s;
+#else
+                s0 = s;
+#endif
+            }
+        }
+    }
+    BB_STAMP(cx, S, 1);
+    BB_SYNC(cx);
+    BB_PASS(cx, tid) {
+        if (tid < KK) {
+#ifdef BB_EMU
+            s0 = lds[L.red + 3 * KKP + tid];
+#endif
+            double s = s0;
+            for (int q = 1; q < NQ; ++q) s += lds[L.red + (q - 1) * KKP + tid];
+            if (tid < M.K) bb_put_total(M, L, lds, tid, s);
+            else lds[L.zgl + (tid - M.K)] = s;
+        }
+    }
+    if (!(KK <= 64 && M.Ttot <= 64)) BB_SYNC(cx);
 }
 
 // ---- cross-GPU leg (XG launches): a group leader stores its group row into EVERY rank's inbox (its own included)

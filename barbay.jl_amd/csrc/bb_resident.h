@@ -158,7 +158,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     Y.eps = Y.hbuf + 4 * P * NT;
     { const int need = racc_total > 6 * P * NT ? racc_total : 6 * P * NT; o += need; }
     L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;     // staging of the cross-GPU inbox rows (bbp_consume<true>): in use while the slot / normals wait
-    L.red = o;     o += 2 * 128 + KK + 16;          // (bbp_consume<.., WIDE>: the second half's partial sums)
+    L.red = o;     o += 2 * 128 + 4 * ((KK + 63) & ~63) + 16;          // (bbp_consume<.., WIDE> / bbp_consume_tg: the second half's partial sums)
     (void)lmax;
     L.total = Y.total = (o + 1) & ~1;
     return Y;
@@ -558,7 +558,7 @@ __device__ __forceinline__ double br_row16_sum(double s) {
 // ---- M: the pairs' differences and moment contributions, summed in the thread over its pair slots (they share the time pair),
 // transposed into LDS; after the barrier 16 lanes per row entry walk their column and a DPP row sum finishes the entry, which
 // goes straight to the tile's published row ------------------------------------------------------------------------------------
-template <int KIND, int P>
+template <int KIND, int P, bool TG = false>
 BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch) {
     double* lds = cx.lds;
     BB_PASS(cx, tid) {
@@ -616,9 +616,23 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
             if (code >> 24) for (int e = c; e < nbt; e += 16) s += col[e * lpb];
             s = br_row16_sum(s);
 #endif
-            if (c == 0) bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
+            if (c == 0) {
+                if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, s, epoch);
+                else bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
+            }
         }
-        for (int j = M.K + tid; j < KK; j += cx.nthr) bb_st<true>(S.prow + (long long)cx.block * KK + j, lds[Y.L.wk + j]);
+        for (int j = M.K + tid; j < KK; j += cx.nthr) {
+            if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch);
+            else bb_st<true>(S.prow + (long long)cx.block * KK + j, lds[Y.L.wk + j]);
+        }
+    }
+    if (TG) {
+        // self-validating entries: no drain, no ready word.  The barrier stays for LDS alone: the contributions' region is about
+        // to take the next normals and the window slot
+        BB_SYNC(cx);
+        BB_STAMP(cx, S, 24);
+        BB_STAMP_RT(cx, S, 29);
+        return;
     }
     bb_drain_and_meet(cx);           // every storing wave has drained its write-through stores
     BB_STAMP(cx, S, 24);
@@ -982,13 +996,17 @@ BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const 
     const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
     // (fetching the members' rows in one round trip -- two waves, 16 members each, partial sums through LDS -- measured SLOWER,
     //  as round 1 had found for k_persist: 7.6 k cycles against 4.8 k for the leader's read + sum + publish)
-    if (cx.block < bbp_groups(A)) bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+    if (cx.block < bbp_groups(A)) {
+        if (!XG && BR_TG) bbp_leader_reduce_tg(cx, M, S, A, (int)(step & 1), epoch, ok_slot);
+        else bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+    }
 }
 template <int KIND, int P, bool XG>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                             unsigned long long step, int* ok_slot) {
     const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
-    bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+    if (!XG && BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot);
+    else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
     br_finish<KIND>(cx, M, S, Y);
 }
 
@@ -1026,7 +1044,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
                 for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
             }
             br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
-            br_moments<KIND, P>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
+            br_moments<KIND, P, !XG && BR_TG>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, step);
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);

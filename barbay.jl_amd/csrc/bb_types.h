@@ -53,6 +53,7 @@ struct DevModel {
 
 #define BB_MAX_WORLD 16               // ranks of one resident multi-GPU run (one xGMI hive holds 8)
 
+struct bb_gran;
 struct DevState {
     double *mu, *om;                  // [D] variational parameters theta = [mu; omega]
     double *zsv, *asv, *hsv;          // [D] per-sample scratch: z, eps*sigmoid(omega) (= dz/domega), sigmoid/softplus (= dH/domega)
@@ -79,6 +80,7 @@ struct DevState {
     unsigned *hstatus;                // host-mapped status words the host reads after a run without a copy: [0] timeout, [1] non-finite state
     double *prow;                     // [nblk][K + 2 nt1] rows of the tiles (persistent launch)
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
+    struct bb_gran *grow, *gxrow;     // k_res on one GPU: the same rows as self-validating 16-byte entries (bb_persist.h, BR_TG): [nblk][K + 2 nt1], [2][16][K + 2 nt1]
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
     const long long *tile_b;          // genotype model, k_res: [tiles + 1] first barcode of every tile (cuts fall on genotype boundaries)
     const int *tile_g;                // genotype model, k_res: [tiles + 1] first genotype every tile owns

@@ -19,6 +19,7 @@ SYNTH = {
     "fitness_T2": ("fitness", dict(B=130, T=2, n_neutral=3)),
     "fitness_T6": ("fitness", dict(B=700, T=6, n_neutral=37)),          # even T: the owner-computes resident launch (k_res), LPB 4 with an idle lane
     "fitness_T4": ("fitness", dict(B=333, T=4, n_neutral=70)),
+    "fitness_wide_grid": ("fitness", dict(B=2100, T=6, n_neutral=90)),      # > 64 tiles of 16 barcodes: the exchange with 32 groups
     "multienv_T6": ("multienv", dict(B=600, T=6, n_env=3, n_neutral=11)),
     "multienv_T8": ("multienv", dict(B=300, T=8, n_env=4, n_neutral=40)),
     "replicate_T6": ("replicate", dict(B=301, T=6, n_rep=2, n_neutral=1)),                 # hierarchical kinds under k_res

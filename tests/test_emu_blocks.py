@@ -118,6 +118,17 @@ def test_owner_computes_launch_sixteen_groups(emu_lib, monkeypatch, name, nb, nt
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("lead", [100, 50])
+def test_owner_computes_launch_thirtytwo_groups(emu_lib, monkeypatch, lead):
+    """self-validating rows with 32 groups (a leader's members fit one batch of eight loads per lane; the consume runs on four
+    thread groups): 132 tiles, uneven member counts."""
+    monkeypatch.setenv("BB_TUNE_NB", "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "256")
+    monkeypatch.setenv("BB_TUNE_NG", "32")
+    monkeypatch.setenv("BB_TUNE_LEAD", str(lead))
+    c.case_persistent_equals_two_kernel(emu_lib, "fitness_wide_grid", expect_kernel=2)
+
+
 @pytest.mark.parametrize("nb,nthr,kernel", [(0, 0, None), (16, 128, 1), (30, 256, 2)])
 def test_owner_computes_launch_long_moment_row(emu_lib, monkeypatch, nb, nthr, kernel):
     """four replicates: the moment row has 198 entries -- more than the two-half consume handles (the exchange keeps 8 groups),

@@ -28,10 +28,11 @@
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct Prm {
     double* prow; double* xrow; unsigned* rdy;            // V0
-    v4u* grow; v4u* gxrow;                            // V2
+    v4u* grow; v4u* gxrow; v4u* grow2;                // V2, V4
     unsigned long long* acc; unsigned* cnt;               // V1: [2][R][KK * 4], [2][R] (one 128-B line each)
     double* out; unsigned* tmo; unsigned long long* stamps;
     int nsteps, nblk, work, jitter, R, epoch0;
+    double* hist; int hmode, W;       // window-slot traffic beside the exchange: 0 none, 1 loads after the publish (k_res today), 2 loads before the step's work
 };
 
 __device__ __forceinline__ double rowval(int b, int step, int k) {
@@ -60,37 +61,51 @@ __device__ __forceinline__ void st16(v4u* p, double v, unsigned tag) {
     v4u g = {lo, tag, hi, tag};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
 }
+__device__ __forceinline__ void st16_plain(v4u* p, double v, unsigned tag) {      // stays in the storing XCD's L2 (dirty): a same-XCD reader's L2 hit
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    v4u g = {lo, tag, hi, tag};
+    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(g) : "memory");
+}
 #define LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(dst) : "v"(ptr) : "memory")
 #define WAIT8(a, o) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), "+v"(a[o + 7]) :: "memory")
 __device__ __forceinline__ void vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ double unpack(v4u g) { return __hiloint2double((int)g.z, (int)g.x); }
 
+#define HLOAD1() do { if (P.hmode == 1) { hm = *(const d2*)(P.hist + hoff); ho = *(const d2*)(P.hist + hoff + (long long)P.nblk * 2048); } } while (0)
 template <int V>
 __global__ void __launch_bounds__(1024) k_xchg(Prm P) {
     extern __shared__ double lds[];
     double* tot = lds;            // [KK]
-    double* red = lds + 64;       // [128]
-    int* ok = (int*)(lds + 200);
+    double* red = lds + 64;       // [256]
+    int* ok = (int*)(lds + 400);
     const int tid = threadIdx.x, b = blockIdx.x;
     if (tid == 0) *ok = 1;
     unsigned long long prev[2] = {0ull, 0ull};
+    unsigned nretry = 0;
     double x = 1.0 + tid * 1e-6;
     __syncthreads();
     long long t_x = 0;
     for (int step = 0; step < P.nsteps; ++step) {
         // ---- stand-in for the step's arithmetic
+        // stand-in for the TruncatedADAGrad window slot: 32 B per thread read per step from a window far larger than the caches, and written back
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 hm = {0.0, 0.0}, ho = {0.0, 0.0};
+        const long long hoff = ((long long)(step % P.W) * 2 * P.nblk + b) * 2048 + 2 * tid;
+        if (P.hmode == 2) { hm = *(const d2*)(P.hist + hoff); ho = *(const d2*)(P.hist + hoff + (long long)P.nblk * 2048); }
         const int n = P.work + (P.jitter ? (int)(hash32((unsigned)(b * 7919 + step * 104729)) % (unsigned)(P.jitter + 1)) : 0);
         for (int i = 0; i < n; ++i) x = fma(x, 0.9999999, 1e-7);
-        if (x == 12345.678) lds[300] = x;
+        if (x == 12345.678) lds[500] = x;
         const unsigned epoch = (unsigned)P.epoch0 + (unsigned)step + 1u;
         const int par = step & 1;
         const double v = tid < KK ? rowval(b, step, tid) : 0.0;
+        __syncthreads();                               // (the tile's row needs every wave's contributions: barrier 2 of the M pass)
         const long long t0 = __builtin_amdgcn_s_memtime();
         if (V == 0) {
             if (tid < KK) st_sc1(P.prow + (long long)b * KK + tid, v);
             vm0();
             __syncthreads();
             if (tid == 0) st_w(P.rdy + 32 * b, epoch);
+            HLOAD1();
             if (b < NG) {
                 const int members = (P.nblk - b + NG - 1) / NG;
                 if (tid < members && !wait_w(P.rdy + 32 * (b + tid * NG), epoch, P.tmo)) *ok = 0;
@@ -126,6 +141,7 @@ __global__ void __launch_bounds__(1024) k_xchg(Prm P) {
         } else if (V == 2 || V == 3) {
             const unsigned tag = epoch;
             if (tid < KK) st16(P.grow + (long long)b * KK + tid, v, tag);
+            HLOAD1();
             if (b < NG && tid < 64) {
                 const int members = (P.nblk - b + NG - 1) / NG;
                 const int k = tid < KK ? tid : KK - 1;
@@ -184,6 +200,70 @@ __global__ void __launch_bounds__(1024) k_xchg(Prm P) {
             __syncthreads();
             if (tid < KK) tot[tid] = s0 + red[tid];
             __syncthreads();
+        } else if (V == 4 || V == 5 || V == 6) {
+            // XCD-local first hop: tiles b with equal b % 8 are ASSUMED to share an XCD (round-robin dispatch; checked by the host from
+            // XCC_ID) -- speed only: every entry is self-validating (V5: a copy stored sc1 backs the local one, the leader polls both).
+            // V4 / V5: tiles -> leader b % 8 through the XCD's L2 (plain stores), then every tile polls the 8 group rows (sc1).
+            // V6: three hops -- local, the 8 leaders among themselves (sc1), local broadcast of the totals row.
+            const unsigned tag = epoch;
+            const int xg = b & 7, nm = (P.nblk - xg + 7) / 8;          // my group, its members b = xg + 8 m
+            if (tid < KK) { st16_plain(P.grow + (long long)b * KK + tid, v, tag); if (V == 5) st16(P.grow2 + (long long)b * KK + tid, v, tag); }
+            if (tid < 64) {
+                const int k = tid < KK ? tid : KK - 1;
+                v4u g[8];
+                if (b < 8) {
+                    double xs = 0.0;
+                    for (int m0 = 0; m0 < nm; m0 += 8) {
+                        unsigned spins = 0;
+                        for (;;) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) LD16(g[i], ((V == 5 && (spins & 1)) ? P.grow2 : P.grow) + (long long)(xg + 8 * (m0 + i < nm ? m0 + i : m0)) * KK + k);
+                            WAIT8(g, 0);
+                            bool good = true;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) good = good && g[i].y == tag && g[i].w == tag;
+                            if (__builtin_amdgcn_ballot_w64(!good) == 0ull) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 255u) == 255u && (ld_w(P.tmo) != 0u || spins > SPIN_LIMIT)) { st_w(P.tmo, 1u); *ok = 0; break; }
+                        }
+                        if (tid == 0) nretry += spins;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) xs += m0 + i < nm ? unpack(g[i]) : 0.0;
+                    }
+                    if (tid < KK) st16(P.gxrow + ((long long)par * NG + b) * KK + tid, xs, tag);       // the group's row, cross-XCD
+                }
+                double s0 = 0.0;
+                if (V != 6 || b < 8) {
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) LD16(g[i], P.gxrow + ((long long)par * NG + i) * KK + k);
+                        WAIT8(g, 0);
+                        bool good = true;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) good = good && g[i].y == tag && g[i].w == tag;
+                        if (__builtin_amdgcn_ballot_w64(!good) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 255u) == 255u && (ld_w(P.tmo) != 0u || spins > SPIN_LIMIT)) { st_w(P.tmo, 1u); *ok = 0; break; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s0 += unpack(g[i]);
+                    if (V == 6 && tid < KK) st16_plain(P.gxrow + ((long long)(2 + par) * NG + b) * KK + tid, s0, tag);   // totals, for my XCD's tiles
+                }
+                if (V == 6 && b >= 8) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        LD16(g[0], P.gxrow + ((long long)(2 + par) * NG + xg) * KK + k);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]) :: "memory");
+                        if (__builtin_amdgcn_ballot_w64(!(g[0].y == tag && g[0].w == tag)) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 255u) == 255u && (ld_w(P.tmo) != 0u || spins > SPIN_LIMIT)) { st_w(P.tmo, 1u); *ok = 0; break; }
+                    }
+                    s0 = unpack(g[0]);
+                }
+                if (tid < KK) tot[tid] = s0;
+            }
+            __syncthreads();
         } else if (V == 1) {
             const int R = P.R, r = b % R;
             const int k = tid >> 2, j = tid & 3;
@@ -205,6 +285,7 @@ __global__ void __launch_bounds__(1024) k_xchg(Prm P) {
             vm0();
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(P.cnt + 32 * (par * R + r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            HLOAD1();
             if (tid < R) {
                 const unsigned members = (unsigned)((P.nblk - tid + R - 1) / R);
                 if (!wait_w(P.cnt + 32 * (par * R + tid), members * (unsigned)(step / 2 + 1), P.tmo)) *ok = 0;
@@ -228,15 +309,22 @@ __global__ void __launch_bounds__(1024) k_xchg(Prm P) {
             if (tid < KK) tot[tid] = ((red[4 * tid + 3] + red[4 * tid + 2]) + red[4 * tid + 1]) + red[4 * tid];
             __syncthreads();
         } else {
+            HLOAD1();
             if (tid < KK) tot[tid] = v;
             __syncthreads();
         }
         t_x += __builtin_amdgcn_s_memtime() - t0;
         if (*ok == 0) break;
         x += tot[tid % KK] * 1e-30;                    // the next step's work depends on the totals
+        if (P.hmode) {
+            x += (hm.x + ho.y) * 1e-30;
+            hm.y += x * 1e-300; ho.x += x * 1e-300;
+            *(d2*)(P.hist + hoff) = hm;
+            *(d2*)(P.hist + hoff + (long long)P.nblk * 2048) = ho;
+        }
     }
     if (tid < KK) P.out[(long long)b * KK + tid] = tot[tid];
-    if (tid == 0) { P.stamps[b] = (unsigned long long)t_x; if (x == 3.0) P.out[0] = x; }
+    if (tid == 0) { P.stamps[b] = (unsigned long long)t_x; P.stamps[P.nblk + b] = ((unsigned long long)nretry << 8) | (unsigned)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15); if (x == 3.0) P.out[0] = x; }
 }
 
 template <int V>
@@ -263,7 +351,7 @@ static double run(Prm P, int nblk, const char* name, bool check) {
     unsigned tmo = 0;
     CK(hipMemcpy(&tmo, P.tmo, 4, hipMemcpyDeviceToHost));
     std::vector<double> out((size_t)nblk * KK);
-    std::vector<unsigned long long> st((size_t)nblk);
+    std::vector<unsigned long long> st((size_t)2 * nblk);
     CK(hipMemcpy(out.data(), P.out, out.size() * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(st.data(), P.stamps, st.size() * 8, hipMemcpyDeviceToHost));
     double maxerr = 0.0;
@@ -283,12 +371,15 @@ static double run(Prm P, int nblk, const char* name, bool check) {
             }
         }
     }
-    std::vector<unsigned long long> s2 = st;
+    std::vector<unsigned long long> s2(st.begin(), st.begin() + nblk);
+    int misplaced = 0; unsigned long long retries = 0;
+    for (int b = 0; b < nblk; ++b) { misplaced += (st[nblk + b] & 15) != (st[nblk + (b & 7)] & 15); retries += st[nblk + b] >> 8; }
     std::sort(s2.begin(), s2.end());
     const double us = ms * 1e3 / P.nsteps;
     printf("%-34s work %5d jitter %5d  %8.3f us/step   exchange cycles/step (median tile) %7.0f   %s", name, P.work, P.jitter, us,
            (double)s2[s2.size() / 2] / P.nsteps, tmo ? "TIMEOUT " : "");
     if (check) printf("max rel err %.2e, tiles differing from tile 0: %d", maxerr, diff);
+    if (V == 4 || V == 5 || V == 6) printf("; tiles NOT on the XCD of tile b %% 8: %d; local polls that needed a retry (all tiles, all steps): %llu", misplaced, retries);
     printf("\n");
     fflush(stdout);
     if (tmo) { unsigned z = 0; CK(hipMemcpy(P.tmo, &z, 4, hipMemcpyHostToDevice)); }
@@ -304,30 +395,40 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&P.xrow, (size_t)2 * NG * KK * 8));
     CK(hipMalloc(&P.rdy, (size_t)32 * (nblk + 2 * NG) * 4));
     CK(hipMalloc(&P.grow, (size_t)nblk * KK * 16));
-    CK(hipMalloc(&P.gxrow, (size_t)2 * NG * KK * 16));
+    CK(hipMalloc(&P.gxrow, (size_t)4 * NG * KK * 16));
     CK(hipMalloc(&P.acc, (size_t)2 * 64 * KK * NLIMB * 8));
     CK(hipMalloc(&P.cnt, (size_t)2 * 64 * 32 * 4));
     CK(hipMalloc(&P.out, (size_t)nblk * KK * 8));
     CK(hipMalloc(&P.tmo, 128));
-    CK(hipMalloc(&P.stamps, (size_t)nblk * 8));
+    CK(hipMalloc(&P.stamps, (size_t)2 * nblk * 8));
+    CK(hipMalloc(&P.grow2, (size_t)nblk * KK * 16));
+    CK(hipMemset(P.grow2, 0, (size_t)nblk * KK * 16));
     CK(hipMemset(P.prow, 0, (size_t)nblk * KK * 8));
     CK(hipMemset(P.xrow, 0, (size_t)2 * NG * KK * 8));
     CK(hipMemset(P.rdy, 0, (size_t)32 * (nblk + 2 * NG) * 4));
     CK(hipMemset(P.grow, 0, (size_t)nblk * KK * 16));
-    CK(hipMemset(P.gxrow, 0, (size_t)2 * NG * KK * 16));
+    CK(hipMemset(P.gxrow, 0, (size_t)4 * NG * KK * 16));
     CK(hipMemset(P.tmo, 0, 128));
     P.nsteps = nsteps;
     P.nblk = nblk;
     P.epoch0 = 1;
-    const int works[3][2] = {{0, 0}, {600, 0}, {600, 300}};
+    P.W = 100;
+    CK(hipMalloc(&P.hist, (size_t)P.W * 2 * nblk * 2048 * 8));
+    CK(hipMemset(P.hist, 0, (size_t)P.W * 2 * nblk * 2048 * 8));
+    const int works[5][3] = {{0, 0, 0}, {0, 0, 1}, {600, 0, 0}, {600, 0, 1}, {600, 0, 2}};
     for (auto& wj : works) {
         P.work = wj[0];
         P.jitter = wj[1];
+        P.hmode = wj[2];
+        printf("---- window-slot traffic mode %d\n", P.hmode);
         run<9>(P, nblk, "no exchange", false);
         P.epoch0 += 100000; run<0>(P, nblk, "V0 flags, 2 hops (today)", true);
         P.epoch0 += 100000; run<2>(P, nblk, "V2a tagged rows, all tiles poll rows", true);
         P.epoch0 += 100000; run<3>(P, nblk, "V2b tagged rows, sentinel poll", true);
-        for (int R : {1, 8, 16, 32}) {
+        P.epoch0 += 100000; run<4>(P, nblk, "V4 XCD-local gather + 8 group rows", true);
+        P.epoch0 += 100000; run<5>(P, nblk, "V5 same, sc1 backup copy polled too", true);
+        P.epoch0 += 100000; run<6>(P, nblk, "V6 local, 8 leaders, local broadcast", true);
+        for (int R : {16}) {
             P.R = R;
             char nm[64];
             snprintf(nm, sizeof nm, "V1 atomics, 1 hop, R = %d", R);
