@@ -345,6 +345,35 @@ BB_DEV BBSlot bb_slot_of(const RunArgs& A, unsigned long long step) {
     return w;
 }
 
+// The resident launches carry the window position from step to step instead of dividing a 64-bit step number three times per
+// step in every wave (the software division was ~60 vector and ~300 scalar instructions of each step: llvm-objdump of the C2
+// instance, round 3): one modulo per launch, then increments -- on scalar registers (the step number is uniform).
+struct BBSlotCtr { int slot, rs; bool past0; };
+BB_DEV int bb_uniform(int v) {
+#if defined(BB_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+BB_DEV BBSlotCtr bb_slot_init(const RunArgs& A, unsigned long long step) {
+    BBSlotCtr c;
+    c.slot = A.opt == 0 ? bb_uniform((int)(step % (unsigned long long)A.W)) : 0;
+    c.rs = (A.opt == 0 && A.resum_every > 1) ? bb_uniform((int)(step % (unsigned long long)A.resum_every)) : 0;
+    c.past0 = bb_uniform(step > 0 ? 1 : 0) != 0;
+    return c;
+}
+BB_DEV BBSlot bb_slot_now(const RunArgs& A, const BBSlotCtr& c) {
+    BBSlot w;
+    w.slot = c.slot;
+    w.resum = A.opt == 0 && (A.resum_every == 1 || (A.resum_every > 1 && c.past0 && c.rs == 0));
+    return w;
+}
+BB_DEV void bb_slot_next(const RunArgs& A, BBSlotCtr& c) {
+    if (A.opt == 0) { c.slot = c.slot + 1 == A.W ? 0 : c.slot + 1; if (A.resum_every > 1) c.rs = c.rs + 1 == A.resum_every ? 0 : c.rs + 1; }
+    c.past0 = true;
+}
+
 // One optimiser update of parameter *p with gradient-of-(-ELBO) d.  which: 0 = mu, 1 = omega.
 // (*acc, *lo): the element's compensated running window sum.
 // a pair's four low-order parts: [mu 0, omega 0, mu 1, omega 1]

@@ -262,6 +262,7 @@ struct bb_handle {
 #endif
     int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
     int res_P = 0;                     // > 0: the launch is k_res (bb_resident.h, owner-computes) with this many pair slots per thread
+    int res_pf = 0;                    // ... when it fetches a step's window slot (RunArgs.pf)
     int res_NB = 0, res_NBL = 0, res_nblk = 0;   // ... its own tile map: barcodes per tile, per leader tile (0: uniform), tiles
     BRLay Yh{};                        // its LDS carve-up (host copy) and device copy
     BRLay* dY = nullptr;
@@ -275,6 +276,11 @@ struct bb_handle {
     double* theta_buf = nullptr;       // genotype model: staging of the theta rows gathered from their owners (theta_sync_*)
     bool theta_stale = false;          // a resident run left the theta_g this shard does not own out of date
     bool in_group = false;             // this handle is a shard of a group: its peers' inboxes are plain pointers, not IPC mappings
+    // genotype model handed over with geno_idx NOT in consecutive runs (utils.data_to_arrays keeps barcodes in order of appearance,
+    // src/utils.jl:692-731): the handle works on the mutants grouped by genotype and presents the caller's order at the ABI.
+    // cidx[i] = the caller's flat index of internal latent i (empty: identity); perm_m[m'] = the caller's mutant of internal mutant m'
+    std::vector<long long> cidx;
+    std::vector<int> perm_m;
     bool force_reduce = false;         // BB_FORCE_ALLREDUCE=1: run the collective path even with one rank (tests)
     bool use_reduce() const { return o.world_size > 1 || M.kind == BB_MODEL_GENOTYPE || force_reduce; }
 };
@@ -363,6 +369,7 @@ static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean,
 
 struct bb_handle;
 static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
+static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
 static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
 static int theta_sync_local(bb_handle* const* hs, int n);
 #ifndef BB_EMU
@@ -529,7 +536,13 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     }
     const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
     if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
-    const BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on);
+    // When the window slot is fetched (RunArgs.pf).  In the exchange's shadow (round 2) its 32 B per latent of HBM reads compete with
+    // the exchange's own loads and stores: at the start of the S pass instead, C2 73.1 -> 77.7 k steps/s, C4 87.1 -> 89.1 k
+    // (profiles/r03b_tagged_rows/prefetch_timing_on_lean_kernel.txt) -- where the slot buffer fits beside the moment contributions
+    int pf = (ev = getenv("BB_TUNE_PF")) ? atoi(ev) : 1;
+    if (pf < 0 || pf > 2 || h->o.optimizer != BB_OPT_TRUNCATED_ADAGRAD) pf = 0;
+    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, pf != 0);
+    if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false); }
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
     bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M));
@@ -552,6 +565,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     h->res_NB = NB;
     h->res_NBL = NBL;
     h->res_nblk = nblk;
+    h->res_pf = pf;
     h->lds_doubles_p = (size_t)Y.total;
     return true;
 }
@@ -654,12 +668,12 @@ static void emu_persist_phase(EmuPersist& E, int phase, long long it, long long 
     } else if (phase == 3) {
         for (int b = 0; b < h->nblk; ++b) {
             BBCtx cx = cxof(b);
-            bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
+            bbp_prefetch_slot<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, bb_slot_of(A, step).slot);
             bbp_residual_ahead<KIND>(cx, h->M, h->NB, A);
             if (xg) bbp_consume<true>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
             else bbp_consume<false>(cx, h->M, h->S, A, L, par, epoch, &E.ok, abs_epoch);
             bbp_finish<KIND>(cx, h->M, h->S, A, h->NB);
-            bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, step);
+            bbp_update<KIND, PP>(cx, h->M, h->S, A, h->NB, st + (size_t)b * h->nthr, bb_slot_of(A, step));
         }
     } else {
         for (int b = 0; b < h->nblk; ++b) {
@@ -685,11 +699,12 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
         if (phase == 0) {
             br_prologue<KIND, PP, AP>(cx, h->M, h->S, A, Y, h->res_NB, sb);
             br_draw_ahead<KIND, PP, AP>(cx, A, Y, sb, (unsigned long long)h->step);
+            if (A.pf == 2) br_prefetch_slot<PP>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, (unsigned long long)h->step).slot);
         } else if (phase == 1) {
-            br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf);
+            br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf, bb_slot_of(A, step).slot);
             if (xg || !BR_TG) br_moments<KIND, PP, false>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
             else br_moments<KIND, PP, true>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, step);
+            br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, step, bb_slot_of(A, step).slot);
         } else if (phase == 2) {
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);
             else br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
@@ -697,9 +712,9 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             if (xg) br_xchg_consume<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             else br_xchg_consume<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
             // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
-            if (!AP && uniform_T(h->M) == 8) br_update<KIND, PP, 8, false>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
-            else if (!AP && uniform_T(h->M) == 6) br_update<KIND, PP, 6, false>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
-            else br_update<KIND, PP, 0, AP>(cx, h->M, h->S, A, Y, sb, step, buf, h->res_NB);
+            if (!AP && uniform_T(h->M) == 8) br_update<KIND, PP, 8, false>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, step), buf, h->res_NB);
+            else if (!AP && uniform_T(h->M) == 6) br_update<KIND, PP, 6, false>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, step), buf, h->res_NB);
+            else br_update<KIND, PP, 0, AP>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, step), buf, h->res_NB);
         } else {
             br_epilogue<KIND, PP, AP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
@@ -757,7 +772,7 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
         bb_handle* h = hs[i];
         es[i].h = h;
         es[i].A = make_args(h, h->step, 0, 1, true, false);
-        if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; es[i].A.ng = h->res_ng; }
+        if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; es[i].A.ng = h->res_ng; es[i].A.pf = h->res_pf; }
         es[i].lds.assign((size_t)std::max(h->nblk, h->res_nblk) * (h->lds_doubles_p + 64), 0.0);
         es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
@@ -800,7 +815,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
     bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M)) : nullptr;
-    if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; A.ng = h->res_ng; }
+    if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; A.ng = h->res_ng; A.pf = h->res_pf; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
@@ -839,7 +854,7 @@ static int check_persistent(bb_handle* h) {
     return 0;
 }
 
-extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
+static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
     if (!md || !opts || !out) return bb_fail(BB_ERR_INVALID, "null argument");
     *out = nullptr;
     if (md->kind < 0 || md->kind > 4) return bb_fail(BB_ERR_INVALID, "unknown model kind %d", md->kind);
@@ -1170,6 +1185,82 @@ extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_h
     return BB_OK;
 }
 
+
+// ---- caller's order <-> the handle's order (genotype model with geno_idx not in runs) ------------------------------------------
+static void perm_gather(const bb_handle* h, const double* caller, double* internal) {
+    const size_t D = h->cidx.size();
+    for (size_t i = 0; i < D; ++i) internal[i] = caller[(size_t)h->cidx[i]];
+}
+static void perm_scatter(const bb_handle* h, const double* internal, double* caller) {
+    const size_t D = h->cidx.size();
+    for (size_t i = 0; i < D; ++i) caller[(size_t)h->cidx[i]] = internal[i];
+}
+
+// The reference hands barcodes over in order of appearance (utils.data_to_arrays, src/utils.jl:692-731), so a genotype's mutants
+// are scattered; the resident launch and genotype-aligned shards need them in consecutive runs (a tile / shard owns whole
+// genotypes and their theta).  The library groups them itself -- a stable sort of the mutants by genotype -- works in that order
+// and presents the caller's at every entry point that takes or returns a latent vector (bb_get_params / posterior / set_params /
+// elbo_grad / logdensity_grad / hier_fitness; bb_get_permutation tells the mapping).  The engine's normal stream is keyed by the
+// INTERNAL index (bb_debug_normals likewise).
+extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
+    if (!md || !opts || !out) return bb_fail(BB_ERR_INVALID, "null argument");
+    bool regroup = md->kind == BB_MODEL_GENOTYPE && md->geno_idx && md->n_bc > 1 && md->n_geno >= 1 && md->n_neutral >= 1 && md->n_time &&
+                   md->counts && md->n_rep == 1 && !getenv("BB_NO_REGROUP");
+    if (regroup) {
+        bool sorted = true, valid = true;
+        for (long long m = 0; m < md->n_bc && valid; ++m) {
+            if (md->geno_idx[m] < 0 || md->geno_idx[m] >= md->n_geno) valid = false;
+            else if (m > 0 && md->geno_idx[m] < md->geno_idx[m - 1]) sorted = false;
+        }
+        regroup = valid && !sorted && md->n_time[0] >= 2 && md->n_time[0] <= 255;      // (anything invalid: create_inner says what)
+    }
+    if (!regroup) return create_inner(md, opts, out);
+    const long long nn = md->n_neutral, nb = md->n_bc, B = nn + nb;
+    const int T = md->n_time[0];
+    std::vector<int> perm((size_t)nb);
+    for (long long m = 0; m < nb; ++m) perm[(size_t)m] = (int)m;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return md->geno_idx[a] < md->geno_idx[b]; });
+    auto src = [&](long long b) { return b < nn ? b : nn + perm[(size_t)(b - nn)]; };
+    std::vector<int64_t> counts2((size_t)B * T);
+    for (long long b = 0; b < B; ++b) memcpy(&counts2[(size_t)b * T], md->counts + src(b) * T, (size_t)T * sizeof(int64_t));
+    std::vector<int32_t> geno2((size_t)nb);
+    for (long long m = 0; m < nb; ++m) geno2[(size_t)m] = md->geno_idx[perm[(size_t)m]];
+    bb_model_desc md2 = *md;
+    md2.counts = counts2.data();
+    md2.geno_idx = geno2.data();
+    // Matrix-form priors of the per-mutant and per-(time, barcode) blocks move with their barcodes
+    std::vector<double> lsm, lss, llm, lls;
+    if (md->logsigma_bc_prior.mean && md->logsigma_bc_prior.std && md->logsigma_bc_prior.n == nb && nb > 1) {
+        lsm.resize((size_t)nb); lss.resize((size_t)nb);
+        for (long long m = 0; m < nb; ++m) { lsm[(size_t)m] = md->logsigma_bc_prior.mean[perm[(size_t)m]]; lss[(size_t)m] = md->logsigma_bc_prior.std[perm[(size_t)m]]; }
+        md2.logsigma_bc_prior.mean = lsm.data(); md2.logsigma_bc_prior.std = lss.data();
+    }
+    if (md->loglambda_prior.mean && md->loglambda_prior.std && md->loglambda_prior.n == (int64_t)B * T && B * T > 1) {
+        llm.resize((size_t)B * T); lls.resize((size_t)B * T);
+        for (long long b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t) { llm[(size_t)b * T + t] = md->loglambda_prior.mean[src(b) * T + t]; lls[(size_t)b * T + t] = md->loglambda_prior.std[src(b) * T + t]; }
+        md2.loglambda_prior.mean = llm.data(); md2.loglambda_prior.std = lls.data();
+    }
+    int rc = create_inner(&md2, opts, out);
+    if (rc) return rc;
+    bb_handle* h = *out;
+    const DevModel& M = h->M;
+    h->perm_m = perm;
+    h->cidx.resize((size_t)M.D);
+    for (long long i = 0; i < M.D; ++i) h->cidx[(size_t)i] = i;
+    for (int k : {BK_TT, BK_LT, BK_LS})
+        for (long long m = 0; m < nb; ++m) h->cidx[(size_t)(M.blk_lo[k] + m)] = M.blk_lo[k] + perm[(size_t)m];
+    for (long long b = nn; b < B; ++b)
+        for (int t = 0; t < T; ++t) h->cidx[(size_t)(M.blk_lo[BK_L] + b * T + t)] = M.blk_lo[BK_L] + src(b) * T + t;
+    return BB_OK;
+}
+
+extern "C" int bb_get_permutation(bb_handle* h, int64_t* caller_index) {
+    if (!h || !caller_index) return bb_fail(BB_ERR_INVALID, "null argument");
+    for (long long i = 0; i < h->M.D; ++i) caller_index[i] = h->cidx.empty() ? i : h->cidx[(size_t)i];
+    return BB_OK;
+}
+
 static void p2p_release(bb_handle* h);
 static void group_destroy(bb_handle* g);
 extern "C" void bb_destroy(bb_handle* h) {
@@ -1496,7 +1587,7 @@ static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
         o.world_size = n;
         o.launch_mode = opts->launch_mode == 1 ? 1 : 0;      // (a shard alone cannot run resident before its inbox is wired: mode 2 is enforced below, on the group)
         bb_handle* sh = nullptr;
-        rc = bb_create(md, &o, &sh);
+        rc = create_inner(md, &o, &sh);
         if (!rc) { sh->in_group = true; g->shards.push_back(sh); }
     }
     if (rc) { group_destroy(g); return rc; }
@@ -1639,6 +1730,12 @@ extern "C" int bb_init_meanfield(bb_handle* h) {
 
 extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega) {
     if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    std::vector<double> pm, po;
+    if (!h->cidx.empty()) {          // the caller's order -> the handle's
+        pm.resize(h->cidx.size()); po.resize(h->cidx.size());
+        perm_gather(h, mu, pm.data()); perm_gather(h, omega, po.data());
+        mu = pm.data(); omega = po.data();
+    }
     if (!h->shards.empty()) { int rc = 0; for (bb_handle* sh : h->shards) if (!rc) rc = bb_set_params(sh, mu, omega); h->step = 0; return rc; }
     BB_ENTER(h);
     int rc;
@@ -1648,14 +1745,23 @@ extern "C" int bb_set_params(bb_handle* h, const double* mu, const double* omega
     return reset_optimizer(h);
 }
 
-extern "C" int bb_get_params(bb_handle* h, double* mu, double* omega) {
-    if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+static int get_params_raw(bb_handle* h, double* mu, double* omega) {
     if (!h->shards.empty()) return group_get_params(h, mu, omega);
     BB_ENTER(h);
     int rc;
     if ((rc = dsync(h->stream))) return rc;
     if ((rc = d2h(mu, h->S.mu, (size_t)h->M.D * 8, h->stream))) return rc;
     return d2h(omega, h->S.om, (size_t)h->M.D * 8, h->stream);
+}
+extern "C" int bb_get_params(bb_handle* h, double* mu, double* omega) {
+    if (!h || !mu || !omega) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (h->cidx.empty()) return get_params_raw(h, mu, omega);
+    std::vector<double> a(h->cidx.size()), b(h->cidx.size());
+    int rc = get_params_raw(h, a.data(), b.data());
+    if (rc) return rc;
+    perm_scatter(h, a.data(), mu);
+    perm_scatter(h, b.data(), omega);
+    return BB_OK;
 }
 
 extern "C" int bb_get_posterior(bb_handle* h, double* mean, double* sigma) {
@@ -1804,8 +1910,25 @@ extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
 #endif
 }
 
+static int elbo_grad_raw(bb_handle* h, const double* mu, const double* omega, const double* eps, int32_t S,
+                         double* elbo, double* grad_mu, double* grad_omega);
 extern "C" int bb_elbo_grad(bb_handle* h, const double* mu, const double* omega, const double* eps, int32_t S,
                             double* elbo, double* grad_mu, double* grad_omega) {
+    if (!h || !mu || !omega || S < 1) return bb_fail(BB_ERR_INVALID, "bad argument");
+    if (h->cidx.empty()) return elbo_grad_raw(h, mu, omega, eps, S, elbo, grad_mu, grad_omega);
+    const size_t D = h->cidx.size();
+    std::vector<double> pm(D), po(D), pe, gm(D), go(D);
+    perm_gather(h, mu, pm.data());
+    perm_gather(h, omega, po.data());
+    if (eps) { pe.resize((size_t)S * D); for (int s = 0; s < S; ++s) perm_gather(h, eps + (size_t)s * D, pe.data() + (size_t)s * D); }
+    int rc = elbo_grad_raw(h, pm.data(), po.data(), eps ? pe.data() : nullptr, S, elbo, grad_mu ? gm.data() : nullptr, grad_omega ? go.data() : nullptr);
+    if (rc) return rc;
+    if (grad_mu) perm_scatter(h, gm.data(), grad_mu);
+    if (grad_omega) perm_scatter(h, go.data(), grad_omega);
+    return BB_OK;
+}
+static int elbo_grad_raw(bb_handle* h, const double* mu, const double* omega, const double* eps, int32_t S,
+                         double* elbo, double* grad_mu, double* grad_omega) {
     if (!h || !mu || !omega || S < 1) return bb_fail(BB_ERR_INVALID, "bad argument");
     BB_GROUP_UNSUPPORTED(h, "bb_elbo_grad");
     BB_ENTER(h);
@@ -2133,7 +2256,18 @@ extern "C" int64_t bb_hier_units(const bb_handle* h) {
     return h->M.blk_hi[BK_TT] - h->M.blk_lo[BK_TT];
 }
 
+static int hier_fitness_raw(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* stdv);
 extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* stdv) {
+    if (!h || !median || !stdv) return bb_fail(BB_ERR_INVALID, "null argument");
+    if (h->perm_m.empty()) return hier_fitness_raw(h, n_samples, seed, median, stdv);
+    const size_t n = h->perm_m.size();          // (genotype model: one unit per mutant)
+    std::vector<double> a(n), b(n);
+    int rc = hier_fitness_raw(h, n_samples, seed, a.data(), b.data());
+    if (rc) return rc;
+    for (size_t m = 0; m < n; ++m) { median[(size_t)h->perm_m[m]] = a[m]; stdv[(size_t)h->perm_m[m]] = b[m]; }
+    return BB_OK;
+}
+static int hier_fitness_raw(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* stdv) {
     if (!h || !median || !stdv) return bb_fail(BB_ERR_INVALID, "null argument");
     if (!h->shards.empty()) {
         // the whole posterior onto shard 0 (entries it does not own are dead weight there: never read by its tiles), then its sampler
@@ -2147,7 +2281,7 @@ extern "C" int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, d
         if (rc) return rc;
         const int ws = s0->o.world_size;
         s0->o.world_size = 1;
-        rc = bb_hier_fitness(s0, n_samples, seed, median, stdv);
+        rc = hier_fitness_raw(s0, n_samples, seed, median, stdv);
         s0->o.world_size = ws;
         return rc;
     }

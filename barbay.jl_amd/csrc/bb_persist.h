@@ -273,7 +273,7 @@ BB_DEV void bbp_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 // lines (and their address translations) are in flight while the workgroup waits for the other tiles ----
 template <int KIND, int P>
 BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
-                              unsigned long long step) {
+                              int slot) {
     const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBSeg* sg = (const BBSeg*)(lds + L.seg);
@@ -281,7 +281,6 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
         if (A.opt == 0) {
-            const int slot = bb_slot_of(A, step).slot;
             const double* hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dp;
             const double* hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
 #pragma unroll
@@ -462,7 +461,7 @@ BB_DEV void bbp_consume_tg(BBCtx& cx, const DevModel& M, const DevState& S, cons
     const int KKP = (KK + 63) & ~63, NQ = (NG + 7) >> 3;
     double s0 = 0.0;
     BB_PASS(cx, tid) {
-        const int q = tid / KKP, kk = tid - q * KKP;
+        const int q = (tid >= KKP ? 1 : 0) + (tid >= 2 * KKP ? 1 : 0) + (tid >= 3 * KKP ? 1 : 0) + (tid >= 4 * KKP ? 1 : 0), kk = tid - q * KKP;      // (no integer division in the step loop)
         if (q < NQ) {
             const bool act = kk < KK;
             const int k = act ? kk : KK - 1, g0 = 8 * q;
@@ -749,7 +748,7 @@ BB_DEV void bbp_finish(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 // ---- second half: residuals, per-latent gradient, optimiser in registers ----------
 template <int KIND, int P>
 BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int NB, BBPst<P>* stv,
-                       unsigned long long step) {
+                       const BBSlot wslot) {
     const BBLds L = bbp_layout<KIND>(cx, M, NB);
     double* lds = cx.lds;
     const BBTile t = bb_tile(M, A, cx.block, NB);
@@ -758,7 +757,6 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     BB_STAMP(cx, S, 26);
     bb_pass_residuals_units<KIND, true>(cx, M, S, L, t, NB);
     BB_STAMP(cx, S, 27);
-    const BBSlot wslot = bb_slot_of(A, step);
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
         // the totals in lds[L.wk ..] have been consumed (F pass): clear the row for the next step's partial sums
@@ -855,14 +853,18 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
     // the step comes from the device counter, not from the host: launches of one bb_run queue back to back, and one that
     // follows a timed-out launch must neither skip steps nor run at all (the timeout word stays set until the host clears it)
     const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
-    const unsigned long long step0 = c0 > c1 ? c0 : c1;   // (the two-kernel step ping-pongs the counter: the current step is the larger word)
+    unsigned long long step0 = c0 > c1 ? c0 : c1;
+    // (uniform: tell the compiler, so that everything derived from the step number -- epoch, parity, window slot -- is scalar work)
+    step0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(step0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)step0);   // (the two-kernel step ping-pongs the counter: the current step is the larger word)
     bbp_prologue<KIND, P>(cx, M, S, A, NB, &st);
     const bool dead = *ok_slot == 0;               // uniform: written by one thread before the prologue's barriers
     int done = 0;
     if (!dead) {
     bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step0);
-    for (; done < nsteps; ++done) {
+    BBSlotCtr sc = bb_slot_init(A, step0);
+    for (; done < nsteps; ++done, bb_slot_next(A, sc)) {
         const unsigned long long step = step0 + (unsigned long long)done;
+        const BBSlot wslot = bb_slot_now(A, sc);
         bbp_sample<KIND, P>(cx, M, S, A, NB, &st, step);
         {
             const BBLds L = bbp_layout<KIND>(cx, M, NB);
@@ -871,13 +873,13 @@ __global__ void __launch_bounds__(NT) k_persist(const DevModel* __restrict__ Mp,
             bbp_publish_row(cx, M, S, L, epoch);                       // wk is complete: bb_pass_moments ended with a barrier
             bbp_draw_ahead<KIND, P>(cx, M, A, NB, &st, step + 1);      // the next step's normals, in the shadow of the rows' flight
             if ((int)blockIdx.x < bbp_groups(A)) bbp_leader_reduce<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);
-            bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, step);    // cold window lines fly while the rows arrive
+            bbp_prefetch_slot<KIND, P>(cx, M, S, A, NB, &st, wslot.slot);    // cold window lines fly while the rows arrive
             bbp_residual_ahead<KIND>(cx, M, NB, A);                    // ... and the totals-independent half of the residuals is tabulated
             bbp_consume<XG>(cx, M, S, A, L, par, epoch, ok_slot, epoch);
             bbp_finish<KIND>(cx, M, S, A, NB);
             if (*ok_slot == 0) break;                                  // uniform: read after the F pass's barrier
         }
-        bbp_update<KIND, P>(cx, M, S, A, NB, &st, step);
+        bbp_update<KIND, P>(cx, M, S, A, NB, &st, wslot);
     }
     }
     bbp_epilogue<KIND, P>(cx, M, S, A, NB, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);

@@ -48,8 +48,8 @@
 
 // (the prior of the segment's block travels with it: read per latent in the G pass, it must come from LDS -- fetched through the
 // model descriptor with a per-lane block index it was a chain of five dependent global loads per pair and step)
-struct BRSeg { long long lo, hi; int tbeg, span, blk, kind, ldsoff, r, lpb, T; double pm, iv; const double* mean_e; const double* iv_e; long long blo; };   // 88 B = 11 doubles
-#define BR_SEG_DOUBLES 11
+struct BRSeg { long long lo, hi; int tbeg, span, blk, kind, ldsoff, r, lpb, T; double pm, iv; const double* mean_e; const double* iv_e; long long blo; int rstride, pad; };   // 96 B = 12 doubles
+#define BR_SEG_DOUBLES 12
 
 struct BRLay {
     BBLds L;             // what the shared exchange / finish code reads: wk, zgl, Lt, invS, cc, wbar, gglob, Dt, elbt, misc, acc, red
@@ -65,8 +65,10 @@ struct BRLay {
                          // cross-GPU inbox staging needs it at the same time
     int racc;            // the moment contributions, transposed: per replicate r [12][rw[r] + 4] at racc_r[r], one column entry per lane
     int racc_r[BB_MAX_REP], rw[BB_MAX_REP];   // of the replicate's loglambda segment (rw = its lanes, whole waves; + 4: the 12 columns start in different banks)
-    int rowmap;          // [K] ints: time-pair class k | value index v << 8 | replicate << 16 | used << 24
+    int rowmap;          // [K] int pairs: {lanes per barcode | used << 24, LDS offset of the entry's column (value v of time-pair class k of replicate r)}
     int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
+    int ftab;            // [Ttot] int4: what the F pass needs of time point j -- {LDS offset of its five moment totals or -1 (a replicate's last
+                         // time point), its index inside s_pop, has a time point before it, -}
     int envt;            // [Ttot] ints: environment of every time point (multienv)
     int gas;             // genotype model: [SU] w As of every mutant of the tile, summed per genotype by the theta threads
     int seg;             // BRSeg table
@@ -74,6 +76,9 @@ struct BRLay {
     int lpb[BB_MAX_REP];
 };
 
+// LDS offset of unit stage table i (the tables are 2 SU apart): arithmetic on two uniform values -- indexed with a per-lane table
+// number, Y.st[i] was a vector load from the layout record in device memory (~500 cycles) inside the S and G passes
+#define BR_ST(Y, i) ((Y).st[0] + (i) * 2 * (Y).SU)
 // lanes per barcode of a loglambda segment: one per pair of time points.  (Any count works: the moment contributions are summed
 // by column walks over the segment's lanes, stride LPB, not by a butterfly over lane bits -- T = 6 used to idle one lane in four.)
 static inline int br_lpb(int T) { return (T + 1) / 2; }
@@ -107,7 +112,7 @@ static inline
 #ifndef BB_EMU
 __host__ __device__
 #endif
-BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
+BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf = false) {
     BRLay Y;
     const int X = (M.kind == 1) ? M.E : (M.kind == 4 ? M.E * M.R : M.R);
     const int KK = M.K + 2 * M.nt1;
@@ -124,7 +129,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     Y.nst = M.kind <= 1 ? 3 : 6;
     for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
     o = (o + 1) & ~1;
-    Y.rowmap = o;  o += (M.K + 1) / 2 + 1;
+    Y.rowmap = o;  o += M.K + 1;          // [K] int pairs
     L.wk = o;      o += KK;
     L.zgl = o;     o += 2 * M.nt1;
     L.Lt = o;      o += M.Ttot;
@@ -139,9 +144,11 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
     L.elbt = o;    o += M.Ttot;
     Y.iG = o;      o += M.Ttot;
     Y.csum = o;    o += BB_MAX_REP;
+    o = (o + 1) & ~1;
+    Y.ftab = o;    o += 2 * M.Ttot;
     Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
     Y.gas = o;     o += M.kind == 2 ? Y.SU : 0;
-    Y.seg = o;     o += BR_SEG_DOUBLES * (BB_MAX_SEG + 1);
+    Y.seg = o;     o += BR_SEG_DOUBLES * (4 + 4 * M.R + 1);      // (br_build_segs: at most R + 1 + 3 R + 2 segments, + the end marker)
     L.seg = Y.seg;
     o = (o + 1) & ~1;
     // One transient region, users that never overlap in time: the transposed moment contributions (M pass -> row sums), then --
@@ -154,9 +161,17 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg) {
         Y.rw[r] = r < M.R ? (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll) : 0;
         if (r < M.R) racc_total += BR_NCV * (Y.rw[r] + 4);
     }
-    Y.hbuf = Y.racc;
-    Y.eps = Y.hbuf + 4 * P * NT;
-    { const int need = racc_total > 6 * P * NT ? racc_total : 6 * P * NT; o += need; }
+    if (own_hbuf) {
+        // the window slot is fetched while the moment contributions are alive (RunArgs.pf = 1, 2): a region of its own
+        Y.eps = Y.racc;
+        { const int need = racc_total > 2 * P * NT ? racc_total : 2 * P * NT; o += need; }
+        o = (o + 1) & ~1;
+        Y.hbuf = o;    o += 4 * P * NT;
+    } else {
+        Y.hbuf = Y.racc;
+        Y.eps = Y.hbuf + 4 * P * NT;
+        { const int need = racc_total > 6 * P * NT ? racc_total : 6 * P * NT; o += need; }
+    }
     L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;     // staging of the cross-GPU inbox rows (bbp_consume<true>): in use while the slot / normals wait
     L.red = o;     o += 2 * 128 + 4 * ((KK + 63) & ~63) + 16;          // (bbp_consume<.., WIDE> / bbp_consume_tg: the second half's partial sums)
     (void)lmax;
@@ -195,6 +210,33 @@ template <bool AP> BB_DEV bool br_pair_aligned(long long i0) { return !AP || !(i
 template <bool AP> BB_DEV bb_d2 br_load_pair(const double* base, long long i0, bool a0, bool a1) {
     if (a0 && a1 && br_pair_aligned<AP>(i0)) return *(const bb_d2*)(base + i0);
     return bb_d2{a0 ? base[i0] : 0.0, a1 ? base[i0 + 1] : 0.0};
+}
+// window slots are written once and read again a whole window (100 steps) later: BR_NT_STORE = 1 stores them non-temporally,
+// BR_NT_LOAD = 2 fetches them with the nt policy (experiment switches; defaults below)
+#ifndef BR_NT_LOAD
+#define BR_NT_LOAD 0
+#endif
+#ifndef BR_PUB_COALESCED
+#define BR_PUB_COALESCED 1
+#endif
+#ifndef BR_NT_STORE
+#define BR_NT_STORE 1
+#endif
+template <bool AP> BB_DEV void br_store_pair_stream(double* base, long long i0, bool a0, bool a1, bb_d2 v) {
+#if !defined(BB_EMU) && BR_NT_STORE
+    if (a0 && a1 && br_pair_aligned<AP>(i0)) {
+        typedef double bb_v2d __attribute__((ext_vector_type(2)));
+        bb_v2d w = {v.x, v.y};
+        __builtin_nontemporal_store(w, (bb_v2d*)(base + i0));
+        return;
+    }
+    if (a0) __builtin_nontemporal_store(v.x, base + i0);
+    if (a1) __builtin_nontemporal_store(v.y, base + i0 + 1);
+#else
+    if (a0 && a1 && br_pair_aligned<AP>(i0)) { *(bb_d2*)(base + i0) = v; return; }
+    if (a0) base[i0] = v.x;
+    if (a1) base[i0 + 1] = v.y;
+#endif
 }
 template <bool AP> BB_DEV void br_store_pair(double* base, long long i0, bool a0, bool a1, bb_d2 v) {
     if (a0 && a1 && br_pair_aligned<AP>(i0)) { *(bb_d2*)(base + i0) = v; return; }
@@ -246,6 +288,7 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
         if (cnt <= 0) return;
         BRSeg s;
         s.lo = lo; s.hi = lo + cnt; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.lpb = lpb; s.T = T;
+        s.rstride = kind == SK_L ? Y.rw[r] + 4 : 0; s.pad = 0;      // (loglambda: stride between the 12 columns of the transposed moment contributions)
         s.pm = M.pri[blk].mean; s.iv = M.pri[blk].inv_var; s.mean_e = M.pri[blk].mean_e; s.iv_e = M.pri[blk].inv_var_e; s.blo = M.blk_lo[blk];
         if (kind == SK_L) { cur = (cur + 63) & ~63; s.span = (int)(cnt / T) * lpb; }   // (T == 0 only for non-loglambda segments)
         else s.span = bb_seg_pairs(lo, lo + cnt);
@@ -310,15 +353,31 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
         int* rm = (int*)(lds + Y.rowmap);
         const int nseg = li[0];
         for (int j = tid; j < M.K; j += cx.nthr) {
-            int code = 0;
+            int code = 0, col = 0;
             for (int r = 0; r < M.R; ++r) {
                 const int T = M.T[r], q0 = j - M.kq[r];
                 if (q0 < 0 || q0 >= 6 * T - 5) continue;
                 int tt, q;
                 if (q0 < T) { tt = q0; q = 0; } else { tt = (q0 - T) / 5; q = 1 + (q0 - T) - 5 * tt; }
-                code = (tt >> 1) | (((tt & 1) * 6 + q) << 8) | (r << 16) | (1 << 24);
+                // (everything the row sums need in ONE LDS read: looked up by replicate in the layout record they were three dependent
+                //  vector loads from device memory behind the code's LDS read, in a pass that is all latency)
+                code = Y.lpb[r] | (1 << 24);
+                col = Y.racc_r[r] + ((tt & 1) * 6 + q) * (Y.rw[r] + 4) + (tt >> 1);
             }
-            rm[j] = code;
+            rm[2 * j] = code;
+            rm[2 * j + 1] = col;
+        }
+        // F-pass table: a lane of the F pass looked its replicate up in the model record -- a chain of four dependent vector loads from
+        // device memory (~2 k cycles) in a pass the whole tile waits for
+        for (int j = tid; j < M.Ttot; j += cx.nthr) {
+            int r = 0;
+            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
+            const int tt = j - M.tcum[r], T = M.T[r];
+            int* ft = (int*)(lds + Y.ftab) + 4 * j;
+            ft[0] = tt < T - 1 ? L.wk + M.kq[r] + T + 5 * tt : -1;
+            ft[1] = M.off_t[r] + tt;
+            ft[2] = tt > 0 ? 1 : 0;
+            ft[3] = 0;
         }
         BRSt<P>& st = BB_PSTATE(stv, tid);
         const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
@@ -465,19 +524,22 @@ template <int KIND> BB_DEV int br_stage_trn(int kind) {
 template <int KIND>
 BB_DEV void br_unit_sw(const double* lds, const BRLay& Y, int buf, int o, int thoff, double* s, double* w) {
     const double* b = lds + buf * Y.SU;
-    if (KIND <= 1) { *s = b[Y.st[0] + o]; *w = b[Y.st[1] + o]; }
-    else { *s = fma(b[Y.st[1] + o], b[Y.st[0] + o], b[Y.st[3] + o - thoff]); *w = b[Y.st[2] + o]; }
+    if (KIND <= 1) { *s = b[BR_ST(Y, 0) + o]; *w = b[BR_ST(Y, 1) + o]; }
+    else { *s = fma(b[BR_ST(Y, 1) + o], b[BR_ST(Y, 0) + o], b[BR_ST(Y, 3) + o - thoff]); *w = b[BR_ST(Y, 2) + o]; }
 }
 
 // ---- S: draw, stage ---------------------------------------------------------------------------------------------------
 // The long fp64 chains (softplus / sigmoid, exp) run for ALL pair slots without a branch, so that the compiler may interleave
 // the slots' chains; only the stores depend on what the pair is.
+template <int P>
+BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int slot);
 template <int KIND, int P>
-BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf) {
+BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf, int slot) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     BB_STAMP(cx, S, 20);
     BB_STAMP_WAVE(cx, S, A, 1);
+    if (A.pf == 1) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
@@ -515,11 +577,11 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 // unit latents: the raw sample (the G pass needs it for the prior term) and, where the (b, t) owners need another
                 // form, that form: logsigma -> w = e^{-2 logsigma}, logtau -> e^{logtau}
                 const int raw = br_stage_raw<KIND>(kind), trn = br_stage_trn<KIND>(kind);
-                double* dst = lds + Y.st[raw] + buf * Y.SU + st.zoff[k];
+                double* dst = lds + BR_ST(Y, raw) + buf * Y.SU + st.zoff[k];
                 if (meta & BRM_A0) dst[0] = st.z[k].x;
                 if (meta & BRM_A1) dst[1] = st.z[k].y;
                 if (trn >= 0) {
-                    double* dw = lds + Y.st[trn] + buf * Y.SU + st.zoff[k];
+                    double* dw = lds + BR_ST(Y, trn) + buf * Y.SU + st.zoff[k];
                     if (meta & BRM_A0) dw[0] = st.lam[k].x;
                     if (meta & BRM_A1) dw[1] = st.lam[k].y;
                 }
@@ -593,7 +655,7 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
             }
             {   // (idle lanes of the segment write zeros: every column entry of its nbt * LPB lanes is fresh each step)
                 const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
-                const int stride = Y.rw[sgk->r] + 4;
+                const int stride = sgk->rstride;
 #pragma unroll
                 for (int q = 0; q < BR_NCV; ++q) lds[st.rb[k] + q * stride] = cv[q];
             }
@@ -607,29 +669,40 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
     BB_PASS(cx, tid) {
         const int c = tid & 15;
         for (int j = tid >> 4; j < M.K; j += cx.nthr >> 4) {
-            const int code = rm[j], kc = code & 255, v = (code >> 8) & 255, r = (code >> 16) & 255, lpb = Y.lpb[r];
-            const double* col = lds + Y.racc_r[r] + v * (Y.rw[r] + 4) + kc;
+            const int code = rm[2 * j], lpb = code & 255;
+            const double* col = lds + rm[2 * j + 1];
             double s = 0.0;
 #ifdef BB_EMU
             if (c == 0 && (code >> 24)) for (int e = 0; e < nbt; ++e) s += col[e * lpb];
 #else
+            // (More reads in flight per lane make this walk SLOWER, three forms tried -- source-level unrolling twice, one asm block of
+            //  four ds_read_b64: pub 2.26 k -> 2.71 k cycles, profiles/r03b_tagged_rows/column_walk_*: it is bound by the LDS pipeline
+            //  under the stride-lpb bank pattern, not by the chain of round trips.)
             if (code >> 24) for (int e = c; e < nbt; e += 16) s += col[e * lpb];
             s = br_row16_sum(s);
 #endif
             if (c == 0) {
-                if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, s, epoch);
+                if (TG && BR_PUB_COALESCED) lds[Y.L.wk + j] = s;
+                else if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, s, epoch);
                 else bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
             }
         }
-        for (int j = M.K + tid; j < KK; j += cx.nthr) {
+        if (!(TG && BR_PUB_COALESCED)) for (int j = M.K + tid; j < KK; j += cx.nthr) {
             if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch);
             else bb_st<true>(S.prow + (long long)cx.block * KK + j, lds[Y.L.wk + j]);
         }
     }
+    // (Measured and dropped, round 3, profiles/r03b_tagged_rows: a light "sentinel" first stage of the polls -- one entry per row until it carries the tag, then the sweep:
+    //  C2 78.8 -> 75.2 k steps/s, the extra round trip costs more than the lighter polling saves.)
     if (TG) {
         // self-validating entries: no drain, no ready word.  The barrier stays for LDS alone: the contributions' region is about
         // to take the next normals and the window slot
         BB_SYNC(cx);
+        if (BR_PUB_COALESCED) {
+            // the row leaves as whole lines from the first waves (one store instruction per 64 entries) instead of one 16-byte
+            // partial line write per entry from a dozen waves
+            BB_PASS(cx, tid) { for (int j = tid; j < KK; j += cx.nthr) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch); }
+        }
         BB_STAMP(cx, S, 24);
         BB_STAMP_RT(cx, S, 29);
         return;
@@ -644,11 +717,10 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
 // exchange.  Every pair slot fetches both halves of its 16-byte pair (the row is padded: an edge pair's outside half is a
 // neighbour's or the padding, never used). --------------------------------------------------------------------------------------
 template <int P>
-BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int slot) {
     if (A.opt != 0) return;
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
-        const int slot = bb_slot_of(A, step).slot;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             if (!(st.meta[k] & BRM_VALID)) continue;
@@ -660,7 +732,7 @@ BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, co
                 dst[tid] = bb_d2{src[0], src[1]};
 #else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + (tid & ~63)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + (tid & ~63)), 16, 0, BR_NT_LOAD);
 #endif
             }
         }
@@ -676,21 +748,20 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
     BB_STAMP_RT(cx, S, 30);
     BB_PASS(cx, tid) {
         for (int j = tid; j < M.Ttot; j += cx.nthr) {
-            int r = 0;
-            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
-            const int tt = j - M.tcum[r], T = M.T[r];
+            const int* ft = (const int*)(lds + Y.ftab) + 4 * j;
+            const int mo = ft[0], zo = ft[1], hasprev = ft[2];
             double Dt = 0.0, c = 0.0, wb = 0.0;
-            if (tt < T - 1) {
+            if (mo >= 0) {
                 const double nn = (double)M.nn;
-                const double* mm = lds + L.wk + M.kq[r] + T + 5 * tt;
+                const double* mm = lds + mo;
                 const double M0 = mm[0], M1 = mm[1], N1 = mm[3], N2 = mm[4];
-                const double sbar = lds[L.zgl + M.off_t[r] + tt], ls = lds[L.zgl + M.nt1 + M.off_t[r] + tt];
+                const double sbar = lds[L.zgl + zo], ls = lds[L.zgl + M.nt1 + zo];
                 wb = bb_exp(-2.0 * ls);
                 c = lds[L.Lt + j + 1] - lds[L.Lt + j] - sbar;
                 const double quadN = N2 - 2.0 * c * N1 + nn * c * c;
                 Dt = (M1 - c * M0) + wb * (N1 - c * nn);
-                lds[L.gglob + M.off_t[r] + tt] = -Dt;
-                lds[L.gglob + M.nt1 + M.off_t[r] + tt] = wb * quadN - nn;
+                lds[L.gglob + zo] = -Dt;
+                lds[L.gglob + M.nt1 + zo] = wb * quadN - nn;
             }
             lds[L.cc + j] = c;
             lds[L.wbar + j] = wb;
@@ -698,7 +769,7 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
             // G_t / S_t with G_t = D_{t-1} - D_t (D == 0 at t == T-1 and before t == 0).  Ttot <= 64 <= nthr: all of this is wave 0,
             // whose LDS operations complete in order (D_{t-1} was stored by lane j-1 in the instruction above); the emulation runs
             // the threads in index order
-            lds[Y.iG + j] = ((tt > 0 ? lds[L.Dt + j - 1] : 0.0) - Dt) * lds[L.invS + j];
+            lds[Y.iG + j] = ((hasprev ? lds[L.Dt + j - 1] : 0.0) - Dt) * lds[L.invS + j];
         }
     }
     BB_SYNC(cx);                     // barrier 3
@@ -815,10 +886,9 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
 // for the loglambda waves and the whole tile waited for them).
 template <int KIND, int P, int TT = 0, bool AP = false>
 BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
-                      unsigned long long step, int buf, int NBs) {
+                      const BBSlot wslot, int buf, int NBs) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
-    const BBSlot wslot = bb_slot_of(A, step);
     // (Measured and dropped: letting a barcode's loglambda lanes also form its units' sums As, Qs -- a DPP sum over the LPB lanes,
     //  two numbers per unit through LDS, one more barrier -- so that the unit threads need not walk the barcode's row: the G pass
     //  is bound by the SIMDs' total VALU work, not by the unit waves; C2 15.3 -> 15.5 us per step, C3 unchanged.)
@@ -857,7 +927,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                     double acc = 0.0;
                     for (int i = 0; i < n; ++i) acc += lds[Y.gas + first + i];
                     (x ? g1 : g0) = acc;
-                    (x ? z1 : z0) = stg[Y.st[3] + st.zoff[k] + x];
+                    (x ? z1 : z0) = stg[BR_ST(Y, 3) + st.zoff[k] + x];
                 }
             } else if (kind < SK_GS) {
                 // Unit latents.  Per unit u = (mutant [, replicate] [, environment]) the sums over the time steps that use it,
@@ -873,7 +943,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                     if (!(x ? a1 : a0)) continue;
                     const int j = st.zoff[k] + x;                      // stage index of the latent
                     const int e = KIND == 2 ? 0 : (st.uo[k][2] >> (8 * x)) & 255, bl = st.uo[k][x];
-                    zx[x] = stg[Y.st[br_stage_raw<KIND>(kind)] + j];
+                    zx[x] = stg[BR_ST(Y, br_stage_raw<KIND>(kind)) + j];
                     // replicates whose rows the latent's gradient sums over: its own; theta: all of them
                     const bool is_th = KIND >= 3 && kind == SK_TH_R;
                     const int r0 = KIND <= 1 ? 0 : (is_th ? 0 : st.pt[k]), r1 = KIND <= 1 ? 1 : (is_th ? M.R : r0 + 1);
@@ -909,10 +979,10 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                         else if (is_th) acc += wv * As;
                         else if (kind == SK_LS_R) acc = wv * Qs - (double)nn;
                         else if (kind == SK_TT_R) {
-                            acc = wv * As * stg[Y.st[1] + j];                                                // e^{logtau}
+                            acc = wv * As * stg[BR_ST(Y, 1) + j];                                                // e^{logtau}
                             if (KIND == 2) lds[Y.gas + j] = wv * As;                                         // d/ds_eff: its genotype's theta sums these
                         }
-                        else acc = wv * As * stg[Y.st[1] + j] * stg[Y.st[0] + j];                            // logtau: e^{logtau} theta_tilde
+                        else acc = wv * As * stg[BR_ST(Y, 1) + j] * stg[BR_ST(Y, 0) + j];                            // logtau: e^{logtau} theta_tilde
                     }
                     gx[x] = acc;
                 }
@@ -948,10 +1018,12 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
                 BR_SCHED_FENCE();
             }
-            if (hs_m) { br_store_pair<AP>(hs_m, st.i0[k], a0, a1, nhm); br_store_pair<AP>(hs_o, st.i0[k], a0, a1, nho); }
+            if (hs_m) { br_store_pair_stream<AP>(hs_m, st.i0[k], a0, a1, nhm); br_store_pair_stream<AP>(hs_o, st.i0[k], a0, a1, nho); }
         }
     }
     }
+    // (the same thread has just read its entries of the slot buffer: its LDS-DMA of the next step's slot may overwrite them)
+    if (A.pf == 2) br_prefetch_slot<P>(cx, M, S, A, Y, stv, wslot.slot + 1 == A.W ? 0 : wslot.slot + 1);
     BB_STAMP_WAVE(cx, S, A, 3);
     BB_STAMP(cx, S, 28);
 }
@@ -984,10 +1056,10 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
 template <int KIND, int P, bool AP = false>
-BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step, int slot) {
     // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
-    br_prefetch_slot<P>(cx, M, S, A, Y, stv, step);
+    if (A.pf == 0) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
     br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(step & 1));          // what of this step's gradient needs no totals
     br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, step + 1);         // the next step's normals, in the shadow of the rows' flight
 }
@@ -1022,7 +1094,9 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
     BRSt<P> st;
     int* ok_slot = (int*)(br_smem + Yp->L.misc) + 1;
     const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
-    const unsigned long long step0 = c0 > c1 ? c0 : c1;
+    unsigned long long step0 = c0 > c1 ? c0 : c1;
+    // (uniform: tell the compiler, so that everything derived from the step number -- epoch, parity, window slot -- is scalar work)
+    step0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(step0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)step0);
     BB_STAMP_RT(cx, S, 2);
     br_prologue<KIND, P, AP>(cx, M, S, A, Y, NB, &st);
     BB_STAMP_RT(cx, S, 3);
@@ -1031,8 +1105,11 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
     if (!dead) {
         br_draw_ahead<KIND, P, AP>(cx, A, Y, &st, step0);
         BB_STAMP_RT(cx, S, 4);
-        for (; done < nsteps; ++done) {
+        BBSlotCtr sc = bb_slot_init(A, step0);
+        if (A.pf == 2) br_prefetch_slot<P>(cx, M, S, A, Y, &st, sc.slot);
+        for (; done < nsteps; ++done, bb_slot_next(A, sc)) {
             const unsigned long long step = step0 + (unsigned long long)done;
+            const BBSlot wslot = bb_slot_now(A, sc);
             const int buf = (int)(step & 1);
             // Several pair slots: the pair descriptors are opaque to the compiler at every step.  Otherwise it hoists the ~15
             // predicates on each of them (kind, valid, mutant, has neighbour ...) out of the step loop as 64-bit lane masks --
@@ -1043,16 +1120,17 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
 #pragma unroll
                 for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
             }
-            br_sample<KIND, P>(cx, M, S, A, Y, &st, buf);
+            br_sample<KIND, P>(cx, M, S, A, Y, &st, buf, wslot.slot);
             br_moments<KIND, P, !XG && BR_TG>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, step);
+            br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, step, wslot.slot);
             br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
             if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
-            br_update<KIND, P, TT, AP>(cx, M, S, A, Y, &st, step, buf, NB);
+            br_update<KIND, P, TT, AP>(cx, M, S, A, Y, &st, wslot, buf, NB);
         }
     }
     BB_STAMP_RT(cx, S, 5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (pf = 2: the slot fetched for a step this launch does not take has landed)
     br_epilogue<KIND, P, AP>(cx, S, &st, step0 + (unsigned long long)done, dead || *ok_slot == 0);
     BB_STAMP_RT(cx, S, 6);
 }

@@ -103,6 +103,8 @@ struct RunArgs {
     int nblk;                         // blocks of the barcode grid
     int nblk_alloc;                   // tiles the exchange / stamp buffers were sized for (+ 8)
     int ng;                           // groups of the exchange's first hop (8; k_res on one GPU: 16 where the tile has the threads for it)
+    int pf;                           // k_res: when a step's TruncatedADAGrad window slot is fetched into LDS -- 0 in the exchange's shadow, 1 at the start of the
+                                      // step's S pass, 2 at the end of the previous step's G pass (1, 2: the slot buffer has an LDS region of its own)
     int nbl;                          // k_res: barcodes of each of the first min(8, nblk) tiles -- the exchange's group leaders get smaller tiles (0: all tiles alike)
     int par;                          // which ctr[] word holds the current step
     int sample, S;

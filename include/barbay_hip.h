@@ -171,6 +171,13 @@ int bb_init_meanfield(bb_handle* h);
  * resets optimiser state and step. */
 int bb_set_params(bb_handle* h, const double* mu, const double* omega);
 int bb_get_params(bb_handle* h, double* mu, double* omega);
+/* Genotype model: the reference hands barcodes over in order of appearance (utils.data_to_arrays, src/utils.jl:692-731), so a
+ * genotype's mutants are scattered over geno_idx.  The library then groups them itself (stable sort of the mutants by genotype:
+ * the resident launch and genotype-aligned shards need consecutive runs), works in that order and presents the CALLER's order at
+ * every entry point that takes or returns a latent vector.  caller_index[i] = the caller's flat index of the handle's internal
+ * latent i (identity when nothing was regrouped); the engine's normal stream (bb_debug_normals, bb_elbo_grad with eps = NULL,
+ * bb_run) is keyed by the INTERNAL index.  caller_index: [bb_num_latents(h)]. */
+int bb_get_permutation(bb_handle* h, int64_t* caller_index);
 
 /* AdvancedVI.optimize!: n_steps iterations of
  *   grad(-ELBO) with S reparameterised samples -> optimiser -> theta -= delta. */

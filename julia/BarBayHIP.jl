@@ -82,8 +82,8 @@ const KIND = Dict("fitness_normal" => 0, "multienv_fitness_normal" => 1, "genoty
     group_genotypes(data; genotype_col=:genotype, neutral_col=:neutral) -> data
 
 Stable reorder of a tidy frame's rows so that the mutant barcodes of one genotype are consecutive (genotypes in order of first
-appearance), to be applied BEFORE `BarBay.utils.data_to_arrays`: the engine's resident launch and its genotype-aligned sharding
-of `genotype_fitness_normal` need `indexin(genotypes, unique(genotypes))` to be non-decreasing (DESIGN.md 3.1, 5).  Results are
+appearance).  NOT needed any more: `bb_create` groups the mutants itself where `geno_idx` is not in consecutive runs and presents
+the caller's order at the ABI (`bb_get_permutation` tells the mapping); kept as a convenience.  Results are
 keyed by barcode id, so the order is the caller's to choose.  (`data_to_arrays` keeps barcodes in order of appearance,
 src/utils.jl:692-731.)  Works on any Tables.jl-style object with `getproperty` columns and `data[perm, :]` indexing (DataFrame).
 """

@@ -46,6 +46,15 @@ def synth(name, seed=5, **pri):
     return fixtures.synthetic(kind, seed=seed, **kw, **pri)
 
 
+def caller_normals(e, seed, step, stream, D):
+    """The engine's normals of (step, stream) in the CALLER's latent order: the stream is keyed by the handle's internal index, which
+    differs from the caller's only where the genotype model's mutants were regrouped inside the library (bb_get_permutation)."""
+    n = rng.normals(seed, step, stream, D)
+    out = np.empty(D)
+    out[e.permutation()] = n
+    return out
+
+
 def check_grad(e, sp, mu, om, eps):
     el, gm, go = literal.elbo_and_grad(mu, om, eps, sp)
     el2, gm2, go2 = e.elbo_grad(mu, om, eps)
@@ -79,14 +88,16 @@ def case_synth_grad(lib, name):
     with make_engine(sp, lib, seed=9) as e:
         mu0, om0 = advi.meanfield_init(9, sp.D)
         m, o = e.get_params()
-        assert np.abs(m - mu0).max() < 1e-13 and np.abs(o - om0).max() < 1e-13
+        cidx = e.permutation()
+        assert np.abs(m[cidx] - mu0).max() < 1e-13 and np.abs(o[cidx] - om0).max() < 1e-13
+        mu0, om0 = m, o
         mu, om = mu0 * 0.2 + 3, om0 * 0.5 - 2
         eps = np.stack([rng.normals(9, 4, s, sp.D) for s in range(3)])
         check_grad(e, sp, mu, om, eps)
         # engine's own Philox stream (eps = NULL) at its current step (0), two samples
         e.set_params(mu, om)
         el3, gm3, go3 = e.elbo_grad(mu, om, None, 2)
-        eps0 = np.stack([rng.normals(9, 0, s, sp.D) for s in range(2)])
+        eps0 = np.stack([caller_normals(e, 9, 0, s, sp.D) for s in range(2)])
         el4, gm4, go4 = literal.elbo_and_grad(mu, om, eps0, sp)
         assert abs(el3 - el4) <= 1e-10 * abs(el4)
         assert np.abs(gm3 - gm4).max() <= 1e-8 * np.abs(gm4).max()
@@ -110,7 +121,8 @@ def _trajectory(lib, sp, nsteps, S, optname, seed=11, use_priors=False, **ekw):
     mu, om = e.get_params()
     opt = advi.TruncatedADAGrad(n=ekw.get("window", 100)) if optname == "TruncatedADAGrad" else advi.DecayedADAGrad()
     f = lambda m, o, eps: literal.elbo_and_grad(m, o, eps, sp)
-    m2, o2, tr = advi.run_advi(sp, f, mu0, om0, nsteps, S, opt, seed)
+    eps_fn = lambda i: np.stack([caller_normals(e, seed, i, s, sp.D) for s in range(S)])
+    m2, o2, tr = advi.run_advi(sp, f, mu0, om0, nsteps, S, opt, seed, eps_fn=eps_fn)
     return e, np.abs(mu - m2).max(), np.abs(om - o2).max(), tr
 
 
@@ -212,6 +224,58 @@ def case_persistent_equals_two_kernel(lib, name, tol=1e-11, expect_kernel=None, 
     assert a < 1e-10 and b < 1e-10, (a, b)
 
 
+def case_genotype_regrouped(lib, name="genotype_runs", seed=6):
+    """geno_idx as the reference hands it over (barcodes in order of appearance, a genotype's mutants scattered;
+    utils.data_to_arrays, src/utils.jl:692-731): the library groups the mutants itself, runs the resident launch and presents the
+    caller's order.  The scatter here interleaves the genotype runs and keeps every genotype's mutants in their relative order, so
+    that the library's stable grouping restores exactly the sorted problem: same draws, bit-equal results after mapping back."""
+    import dataclasses
+    sp = synth(name, seed=seed)
+    g = np.random.default_rng(3)
+    gi = np.asarray(sp.geno_idx)
+    order = np.argsort(g.random(sp.n_bc) + 1e-9 * np.arange(sp.n_bc), kind="stable")       # a random merge ...
+    keys = np.sort(g.random(sp.n_bc))
+    # ... that keeps each genotype's mutants in order: give mutant m the m-th smallest key among its genotype's draws
+    shuffled = np.empty(sp.n_bc, dtype=np.int64)       # shuffled[j] = sorted-problem mutant at caller position j
+    pos_keys = g.random(sp.n_bc)
+    for gg in np.unique(gi):
+        mem = np.nonzero(gi == gg)[0]
+        pos_keys[mem] = np.sort(pos_keys[mem])
+    shuffled = np.argsort(pos_keys, kind="stable")
+    nn = sp.n_neutral
+    cols = np.concatenate([np.arange(nn), nn + shuffled])
+    sp2 = dataclasses.replace(sp, counts=[c[:, cols] for c in sp.counts], geno_idx=gi[shuffled])
+    assert not np.all(np.diff(np.asarray(sp2.geno_idx)) >= 0)
+    kw = dict(seed=13, window=6, resum_every=1)
+    with make_engine(sp, lib, launch_mode=2, **kw) as e:
+        e.run(11)
+        ref = e.get_params()
+        assert (e.permutation() == np.arange(sp.D)).all()
+    with make_engine(sp2, lib, launch_mode=2, **kw) as e:
+        assert e.stats()["resident_kernel"] == 2
+        cidx = e.permutation()
+        mu0, om0 = e.get_params()
+        # gradient at a fixed point with explicit draws, in the caller's order, against the literal oracle on the scattered problem
+        eps = np.stack([rng.normals(5, 1, s_, sp.D) for s_ in range(2)])
+        check_grad(e, sp2, mu0 * 0.3 + 2, om0 * 0.5 - 1, eps)
+        e.run(11)
+        got = e.get_params()
+        med, sd = e.hier_fitness(300, seed=4)
+    # internal latent i of the scattered handle IS latent i of the sorted problem
+    assert (got[0][cidx] == ref[0]).all() and (got[1][cidx] == ref[1]).all()
+    off = sp.offsets()
+    lo_tt = off["theta_tilde"][0]
+    with make_engine(sp, lib, launch_mode=2, **kw) as e:
+        e.run(11)
+        med1, sd1 = e.hier_fitness(300, seed=4)
+    pu = cidx[lo_tt:lo_tt + sp.n_bc] - lo_tt
+    assert (med[pu] == med1).all() and (sd[pu] == sd1).all()
+    # trajectory against the oracle loop on the scattered problem (draws mapped through the permutation)
+    e, a, b, _ = _trajectory(lib, sp2, 9, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
+    e.close()
+    assert a < 1e-10 and b < 1e-10, (a, b)
+
+
 def case_ragged_method(lib, launch_mode=0):
     """BB_FLAG_RAGGED_METHOD reproduces the ragged replicate method's neutral pairing exactly as the reference
     writes it (oracle/literal.py ragged_quirk=True, model_fitness_normal_hierarchical_replicates.jl:596-610)."""
@@ -252,12 +316,14 @@ def case_hier_fitness(lib, name):
         (lo_th, hi_th), (lo_tt, hi_tt), (lo_lt, _) = off["theta"], off["theta_tilde"], off["logtau"]
         n_units = hi_tt - lo_tt
         idx = np.asarray(sp.geno_idx) if sp.kind == "genotype" else np.arange(n_units) % (hi_th - lo_th)
+        # (the per-unit draws are keyed by the handle's INTERNAL unit number: pu[u'] = the caller's unit of internal unit u')
+        pu = e.permutation()[lo_tt:hi_tt] - lo_tt
         for n in (1000, 777):
             med, sd = e.hier_fitness(n, seed=21)
-            med2, sd2 = rng.hier_fitness(21, n, idx[:40], mean[lo_th:hi_th], sigma[lo_th:hi_th], mean[lo_lt:lo_lt + n_units],
-                                         sigma[lo_lt:lo_lt + n_units], mean[lo_tt:hi_tt], sigma[lo_tt:hi_tt])
+            med2, sd2 = rng.hier_fitness(21, n, idx[pu][:40], mean[lo_th:hi_th], sigma[lo_th:hi_th], mean[lo_lt:lo_lt + n_units][pu],
+                                         sigma[lo_lt:lo_lt + n_units][pu], mean[lo_tt:hi_tt][pu], sigma[lo_tt:hi_tt][pu])
             assert med.shape == (n_units,)
-            assert np.abs(med[:40] - med2).max() < 1e-10 and np.abs(sd[:40] - sd2).max() < 1e-10
+            assert np.abs(med[pu][:40] - med2).max() < 1e-10 and np.abs(sd[pu][:40] - sd2).max() < 1e-10
         med, sd = e.hier_fitness(10_000, seed=5)
         g = np.random.default_rng(0)
         u = 7

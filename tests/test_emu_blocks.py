@@ -202,8 +202,17 @@ def test_genotype_empty_genotypes_and_unsorted(emu_lib, monkeypatch):
             if mode == 2:
                 assert e.stats()["resident_kernel"] == 2
     assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-11 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-11
+    # geno_idx that is not in consecutive runs: the library regroups the mutants itself (BB_NO_REGROUP=1: the two-kernel step stays)
+    with make_engine(c.synth("genotype"), emu_lib, launch_mode=2) as e:
+        assert e.stats()["resident_kernel"] == 2 and not (e.permutation() == np.arange(e.D)).all()
+    monkeypatch.setenv("BB_NO_REGROUP", "1")
     with pytest.raises(bb.BarBayHipError, match="consecutive runs"):
         make_engine(c.synth("genotype"), emu_lib, launch_mode=2)
+
+
+@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8", "genotype_odd"])
+def test_genotype_regrouped_inside_the_library(emu_lib, name):
+    c.case_genotype_regrouped(emu_lib, name)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -243,8 +252,6 @@ def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):
 def test_persistent_not_eligible_is_an_error(emu_lib):
     import barbay_jl_amd as bb
     from conftest import make_engine
-    with pytest.raises(bb.BarBayHipError, match="persistent"):
-        make_engine(c.synth("genotype"), emu_lib, launch_mode=2)
     with pytest.raises(bb.BarBayHipError, match="samples_per_step"):
         make_engine(c.synth("multienv"), emu_lib, launch_mode=2, samples_per_step=2)
 
@@ -365,7 +372,7 @@ def test_multi_device_handle_launch_mode_2(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NTHR", "256")
     c.case_multi_device_handle(emu_lib, "fitness_T6", 2, launch_mode=2)
     with pytest.raises(bb.BarBayHipError, match="launch_mode = 2"):
-        make_engine(c.synth("genotype"), emu_lib, device_ids=[0, 0], launch_mode=2)
+        make_engine(c.synth("multienv"), emu_lib, device_ids=[0, 0], launch_mode=2, samples_per_step=2)
 
 
 def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeypatch):
@@ -373,4 +380,4 @@ def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeyp
     monkeypatch.setenv("BB_TUNE_NB", "16")
     monkeypatch.setenv("BB_TUNE_NTHR", "256")
     c.case_multi_device_handle(emu_lib, "multienv", 2, expect_resident=False, launch_mode=1)
-    c.case_multi_device_handle(emu_lib, "genotype", 3, expect_resident=False)
+    c.case_multi_device_handle(emu_lib, "genotype", 3, expect_resident=False)     # (genotypes of ~32 mutants do not fit these 16-barcode tiles)

@@ -289,6 +289,14 @@ def test_owner_computes_launch_genotype(hip_lib, name):
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8", "genotype_odd"])
+def test_genotype_regrouped_inside_the_library(hip_lib, name):
+    """geno_idx in order of appearance (a genotype's mutants scattered, as utils.data_to_arrays delivers them): regrouped by the
+    library, resident launch, caller's order at the ABI -- bit-equal to the sorted problem, gradient and trajectory against the
+    literal oracle on the scattered problem."""
+    c.case_genotype_regrouped(hip_lib, name)
+
+
 @pytest.mark.parametrize("name", ["genotype_odd", "replicate_odd"])
 def test_owner_computes_launch_odd_loglambda_offset(hip_lib, monkeypatch, name):
     """loglambda starting at an odd flat index: a k_res pair takes its normals from two Philox pairs and moves as 8-byte
