@@ -138,6 +138,7 @@ BB_DEV void bb_prior_of(const DevModel& M, int blk, long long j, double* mean, d
 struct BBLds {
     int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg, zgl, lam;
     int total;
+    int tmap;       // k_res: [K] ints, the time point (index into Lt / invS) whose normaliser S_t row entry k is, or -1 (0: no table, bb_put_total searches)
 };
 
 template <int KIND> BB_DEV int bb_xdim(const DevModel& M) { return KIND == 1 ? M.E : (KIND == 4 ? M.E * M.R : M.R); }
@@ -178,6 +179,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.lam = o;  o += with_lam ? NB * Ttot : 0;   // exp(loglambda sample) of the tile (resident launch only)
     L.res = o;  o += with_lam ? NB * Ttot : 0;   // a_tb = (l[t+1] - l[t]) - s_eff, filled in the exchange's shadow (resident launch only)
     L.total = (o + 1) & ~1;
+    L.tmap = 0;
     return L;
 }
 
@@ -743,6 +745,11 @@ BB_DEV void bb_block_sample(BBCtx& cx, const DevModel& M, const DevState& S, con
 // A finished total: store it; the S_t rows also yield 1/S_t and L_t = log S_t on the spot (saves a pass + barrier).
 BB_DEV void bb_put_total(const DevModel& M, const BBLds& L, double* lds, int k, double s) {
     lds[L.wk + k] = s;
+    if (L.tmap) {       // (k_res: one LDS read instead of a search through the model record -- a chain of dependent scalar loads per replicate)
+        const int j = ((const int*)(lds + L.tmap))[k];
+        if (j >= 0) { lds[L.invS + j] = bb_rcp(s); lds[L.Lt + j] = bb_log(s); }
+        return;
+    }
     for (int r = 0; r < M.R; ++r) {
         const int tt = k - M.kq[r];
         if (tt >= 0 && tt < M.T[r]) {

@@ -397,9 +397,9 @@ static int uniform_T(const DevModel& M) {
 }
 
 #ifndef BB_EMU
-static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool ap) {
+static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool ap, bool ms = false) {
 #ifdef BB_FAST_BUILD
-    if (xg) return nullptr;
+    if (xg || ms) return nullptr;
     if (ap) {
         if (nthr > 512 && P == 1 && kind == 0) return k_res<0, 1, 1024, false, 0, true>;
         if (nthr > 256 && nthr <= 512 && P == 3 && kind == 3) return k_res<3, 3, 512, false, 0, true>;
@@ -413,12 +413,13 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool 
     if (nthr > 512 && P == 1 && kind == 2) return T == 8 ? k_res<2, 1, 1024, false, 8> : k_res<2, 1, 1024, false>;
     return nullptr;
 #else
+    if (ms && xg) return nullptr;              // (several samples per step / ELBO recording: single-GPU instances only)
     switch (kind) {
-    case 0: return bb_res_instance_k0(P, nthr, xg, T, ap);
-    case 1: return bb_res_instance_k1(P, nthr, xg, T, ap);
-    case 2: return bb_res_instance_k2(P, nthr, xg, T, ap);
-    case 3: return bb_res_instance_k3(P, nthr, xg, T, ap);
-    default: return bb_res_instance_k4(P, nthr, xg, T, ap);
+    case 0: return bb_res_instance_k0(P, nthr, xg, T, ap, ms);
+    case 1: return bb_res_instance_k1(P, nthr, xg, T, ap, ms);
+    case 2: return bb_res_instance_k2(P, nthr, xg, T, ap, ms);
+    case 3: return bb_res_instance_k3(P, nthr, xg, T, ap, ms);
+    default: return bb_res_instance_k4(P, nthr, xg, T, ap, ms);
     }
 #endif
 }
@@ -545,7 +546,8 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false); }
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
-    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M));
+    const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
+    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), ms);
     if (!k) return false;
     const int lds = Y.total * 8;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
@@ -575,13 +577,15 @@ static int setup_persistent(bb_handle* h) {
     const char* ev = getenv("BB_NO_PERSIST");
     const bool want = h->o.launch_mode != 1 && !(ev && atoi(ev) > 0 && h->o.launch_mode == 0);
     const char* why = nullptr;
-    if (h->o.samples_per_step != 1) why = "samples_per_step != 1";
-    else if (h->force_reduce || (h->o.world_size != 1 && !h->p2p_on)) why = "sharded run";
+    // several MC samples per step (Turing.ADVI(samples_per_step, ..), src/vi.jl:98) and ELBO recording: k_res's MS instances, on one GPU
+    const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
+    if (h->force_reduce || (h->o.world_size != 1 && !h->p2p_on)) why = "sharded run";
     else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";   // (k_res's own tile map never has fewer tiles than this one)
-    else if (h->o.elbo_every != 0) why = "ELBO recording is on";
+    else if (ms && h->p2p_on) why = h->o.samples_per_step != 1 ? "samples_per_step != 1 on a sharded run" : "ELBO recording is on (sharded run)";
     h->res_P = 0;
-    const bool ap_first = h->M.kind == BB_MODEL_GENOTYPE || (getenv("BB_TUNE_AP") && atoi(getenv("BB_TUNE_AP")) > 0);
+    const bool ap_first = ms || h->M.kind == BB_MODEL_GENOTYPE || (getenv("BB_TUNE_AP") && atoi(getenv("BB_TUNE_AP")) > 0);
     if (!why && want && try_resident(h, ap_first)) { h->persist_P = h->res_P; return 0; }
+    if (!why && ms) why = h->o.samples_per_step != 1 ? "samples_per_step != 1 and the shape has no owner-computes instance" : "ELBO recording is on and the shape has no owner-computes instance";
     if (!why && h->M.kind == BB_MODEL_GENOTYPE)
         why = h->M.geno_sorted ? "genotype model: no tile map with whole genotypes per tile fits the device" : "genotype model: geno_idx is not in consecutive runs (a tile must hold whole genotypes)";
     int P = 0;
@@ -614,7 +618,7 @@ static int setup_persistent(bb_handle* h) {
     if (why) {
         // k_persist cannot (tile too large for its state, no instance, sharded with more than one pair per thread ...): k_res's
         // any-parity instances as the second chance
-        const bool structural = h->o.samples_per_step != 1 || h->o.elbo_every != 0 || h->force_reduce || (h->o.world_size != 1 && !h->p2p_on) || (h->p2p_on && h->nblk < 8);
+        const bool structural = ms || h->force_reduce || (h->o.world_size != 1 && !h->p2p_on) || (h->p2p_on && h->nblk < 8);
         if (want && !structural && !ap_first && try_resident(h, true)) { h->persist_P = h->res_P; return 0; }
         if (h->o.launch_mode == 2) return bb_fail(BB_ERR_UNSUPPORTED, "launch_mode = 2 (persistent) not possible: %s", why);
         return 0;
@@ -690,9 +694,18 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
     BRSt<PP>* st = (BRSt<PP>*)E.st.data();
     auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), nullptr}; };
     const BRLay& Y = h->Yh;
-    const unsigned long long step = (unsigned long long)(h->step + it);
-    const int buf = (int)(step & 1);
+    // `it` counts the exchanges of this run: step (h->step + it / NS), sample it % NS (the MS instances' arithmetic; NS == 1 otherwise)
+    const int NS = A.S < 1 ? 1 : A.S;
+    const bool MSrun = NS > 1 || A.elbo_every > 0;
+    const unsigned long long step = (unsigned long long)(h->step + it / NS);
+    const int smp = (int)(it % NS);
+    const bool last = smp == NS - 1;
+    const unsigned long long xc = MSrun ? step * (unsigned long long)NS + (unsigned long long)smp : step;
+    const int buf = (int)(xc & 1);
+    const bool want_el = MSrun && A.elbo_every > 0 && step % (unsigned long long)A.elbo_every == 0;
+    const int ring = A.elbo_every > 0 ? (int)((step / (unsigned long long)A.elbo_every) % BB_ELBO_RING) : 0;
     const bool xg = h->p2p_on;
+    const BBSlot wslot = bb_slot_of(A, step);
     for (int b = 0; b < (phase == 2 ? bbp_groups(A) : h->res_nblk); ++b) {
         BBCtx cx = cxof(b);
         BRSt<PP>* sb = st + (size_t)b * h->nthr;
@@ -701,20 +714,24 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             br_draw_ahead<KIND, PP, AP>(cx, A, Y, sb, (unsigned long long)h->step);
             if (A.pf == 2) br_prefetch_slot<PP>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, (unsigned long long)h->step).slot);
         } else if (phase == 1) {
-            br_sample<KIND, PP>(cx, h->M, h->S, A, Y, sb, buf, bb_slot_of(A, step).slot);
-            if (xg || !BR_TG) br_moments<KIND, PP, false>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
-            else br_moments<KIND, PP, true>(cx, h->M, h->S, Y, sb, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, step, bb_slot_of(A, step).slot);
+            if (MSrun) br_sample<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, buf, wslot.slot, last, want_el);
+            else br_sample<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, buf, wslot.slot);
+            const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
+            if (xg || !BR_TG) { if (MSrun) br_moments<KIND, PP, false, true>(cx, h->M, h->S, Y, sb, buf, epoch, want_el); else br_moments<KIND, PP, false, false>(cx, h->M, h->S, Y, sb, buf, epoch); }
+            else { if (MSrun) br_moments<KIND, PP, true, true>(cx, h->M, h->S, Y, sb, buf, epoch, want_el); else br_moments<KIND, PP, true, false>(cx, h->M, h->S, Y, sb, buf, epoch); }
+            br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
         } else if (phase == 2) {
-            if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, step, &E.ok);
-            else br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
+            if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, xc, &E.ok);
+            else br_xchg_lead<false>(cx, h->M, h->S, A, Y, xc, &E.ok);
         } else if (phase == 3) {
-            if (xg) br_xchg_consume<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
-            else br_xchg_consume<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, step, &E.ok);
+            if (xg) br_xchg_consume<KIND, PP, true, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok);
+            else if (MSrun) br_xchg_consume<KIND, PP, false, true>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, want_el, ring, smp);
+            else br_xchg_consume<KIND, PP, false, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok);
             // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
-            if (!AP && uniform_T(h->M) == 8) br_update<KIND, PP, 8, false>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, step), buf, h->res_NB);
-            else if (!AP && uniform_T(h->M) == 6) br_update<KIND, PP, 6, false>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, step), buf, h->res_NB);
-            else br_update<KIND, PP, 0, AP>(cx, h->M, h->S, A, Y, sb, bb_slot_of(A, step), buf, h->res_NB);
+            if (MSrun) br_update<KIND, PP, 0, AP, true>(cx, h->M, h->S, A, Y, sb, wslot, buf, h->res_NB, smp, NS);
+            else if (!AP && uniform_T(h->M) == 8) br_update<KIND, PP, 8, false>(cx, h->M, h->S, A, Y, sb, wslot, buf, h->res_NB);
+            else if (!AP && uniform_T(h->M) == 6) br_update<KIND, PP, 6, false>(cx, h->M, h->S, A, Y, sb, wslot, buf, h->res_NB);
+            else br_update<KIND, PP, 0, AP>(cx, h->M, h->S, A, Y, sb, wslot, buf, h->res_NB);
         } else {
             br_epilogue<KIND, PP, AP>(cx, h->S, sb, (unsigned long long)(h->step + nsteps), E.ok == 0);
         }
@@ -771,13 +788,14 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
     for (int i = 0; i < n; ++i) {
         bb_handle* h = hs[i];
         es[i].h = h;
-        es[i].A = make_args(h, h->step, 0, 1, true, false);
+        es[i].A = make_args(h, h->step, 0, h->res_P ? h->o.samples_per_step : 1, true, false);
         if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; es[i].A.ng = h->res_ng; es[i].A.pf = h->res_pf; }
         es[i].lds.assign((size_t)std::max(h->nblk, h->res_nblk) * (h->lds_doubles_p + 64), 0.0);
         es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
     }
-    for (long long it = 0; it < nsteps; ++it)
+    const long long NS = hs[0]->res_P ? std::max(hs[0]->o.samples_per_step, 1) : 1;
+    for (long long it = 0; it < nsteps * NS; ++it)
         for (int phase = 1; phase <= 3; ++phase)
             for (int i = 0; i < n; ++i) emu_persist_dispatch(es[i], phase, it, nsteps);
     int rc = 0;
@@ -794,17 +812,18 @@ extern "C" int bb_emu_run_group(bb_handle** hs, int32_t n, int64_t nsteps) {
     if (!hs || n < 1 || nsteps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
     for (int i = 0; i < n; ++i)
         if (!hs[i] || hs[i]->persist_P == 0) return bb_fail(BB_ERR_INVALID, "handle %d has no resident launch", i);
-    for (int i = 0; i < n; ++i) hs[i]->req_steps += nsteps;
+    for (int i = 0; i < n; ++i) hs[i]->req_steps += nsteps * std::max(hs[i]->o.samples_per_step, 1);
     int rc = emu_run_group(hs, n, nsteps);
     if (!rc) rc = theta_sync_local(hs, n);          // (genotype model: theta_g back from its owner, as bb_run does through RCCL)
     return rc;
 }
 #endif
 
+static bool res_ms(const bb_handle* h) { return h->res_P > 0 && (h->o.samples_per_step != 1 || h->o.elbo_every != 0); }
 static int launch_persistent(bb_handle* h, long long nsteps) {
-    RunArgs A = make_args(h, h->step, 0, 1, true, false);
+    RunArgs A = make_args(h, h->step, 0, h->res_P ? h->o.samples_per_step : 1, true, false);
     int rc = 0;
-    h->req_steps += nsteps;
+    h->req_steps += nsteps * (h->res_P ? std::max(h->o.samples_per_step, 1) : 1);      // (exchanges asked: the rows' epochs count them)
 #ifdef BB_EMU
     (void)A;
     if (h->p2p_on) return bb_fail(BB_ERR_UNSUPPORTED, "emulation: step the ranks of a sharded resident run with bb_emu_run_group");
@@ -814,7 +833,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
-    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M)) : nullptr;
+    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), res_ms(h)) : nullptr;
     if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; A.ng = h->res_ng; A.pf = h->res_pf; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
@@ -1642,7 +1661,7 @@ static int group_run(bb_handle* g, int64_t n_steps) {
     int rc = 0;
     if (g->group_resident) {
 #ifdef BB_EMU
-        for (bb_handle* sh : g->shards) sh->req_steps += n_steps;
+        for (bb_handle* sh : g->shards) sh->req_steps += n_steps * std::max(sh->o.samples_per_step, 1);
         rc = emu_run_group(g->shards.data(), (int)g->shards.size(), n_steps);      // the emulation steps the shards in lock step
         if (!rc) rc = theta_sync_local(g->shards.data(), (int)g->shards.size());
         g->step = g->shards[0]->step;

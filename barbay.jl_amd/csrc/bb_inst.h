@@ -9,11 +9,11 @@ typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*
 typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, RunArgs, int, int);
 #define BB_INST __attribute__((visibility("hidden")))
 BB_INST bb_persist_kernel bb_persist_instance(int kind, int P, int nthr, bool xg);
-// k_res<KIND, P, NT, XG, TT, AP>: T = the model's common time-point count (0: replicates differ), compile-time in the BASELINE
-// shapes; ap = br_any_parity(model)
-BB_INST bb_res_kernel bb_res_instance_k0(int P, int nthr, bool xg, int T, bool ap);
-BB_INST bb_res_kernel bb_res_instance_k1(int P, int nthr, bool xg, int T, bool ap);
-BB_INST bb_res_kernel bb_res_instance_k2(int P, int nthr, bool xg, int T, bool ap);
-BB_INST bb_res_kernel bb_res_instance_k3(int P, int nthr, bool xg, int T, bool ap);
-BB_INST bb_res_kernel bb_res_instance_k4(int P, int nthr, bool xg, int T, bool ap);
+// k_res<KIND, P, NT, XG, TT, AP, MS>: T = the model's common time-point count (0: replicates differ), compile-time in the BASELINE
+// shapes; ap = br_any_parity(model); ms = several MC samples per step and / or ELBO recording (single-GPU, generic-T instances)
+BB_INST bb_res_kernel bb_res_instance_k0(int P, int nthr, bool xg, int T, bool ap, bool ms);
+BB_INST bb_res_kernel bb_res_instance_k1(int P, int nthr, bool xg, int T, bool ap, bool ms);
+BB_INST bb_res_kernel bb_res_instance_k2(int P, int nthr, bool xg, int T, bool ap, bool ms);
+BB_INST bb_res_kernel bb_res_instance_k3(int P, int nthr, bool xg, int T, bool ap, bool ms);
+BB_INST bb_res_kernel bb_res_instance_k4(int P, int nthr, bool xg, int T, bool ap, bool ms);
 #endif

@@ -57,6 +57,7 @@ struct BRLay {
     int zr0[BB_MAX_REP]; // T_r + 1 doubles apart: with the natural stride T_r (8: 64 B) the unit threads' walks along their barcodes'
                          // rows (two barcodes per lane) land all 64 lanes in two banks -- measured: the unit waves' G pass took
                          // 14 k cycles against 5 k for the loglambda waves
+    int zlw, stw;        // buffers of zl and of every stage table (2: double-buffered by step parity; k_stream: 1), stage-table stride zlw x SU
     int st[6], SU, nst;  // nst unit stage tables, each [2][SU]: fitness / multienv  0 = s, 1 = w = e^{-2 logsigma}, 2 = logsigma
                          //   hierarchical  0 = theta_tilde, 1 = e^logtau, 2 = w, 3 = theta, 4 = logtau, 5 = logsigma
     int eps;             // [P * NT] bb_d2: the next step's normals
@@ -76,9 +77,9 @@ struct BRLay {
     int lpb[BB_MAX_REP];
 };
 
-// LDS offset of unit stage table i (the tables are 2 SU apart): arithmetic on two uniform values -- indexed with a per-lane table
+// LDS offset of unit stage table i (the tables are stw = 2 SU apart): arithmetic on two uniform values -- indexed with a per-lane table
 // number, Y.st[i] was a vector load from the layout record in device memory (~500 cycles) inside the S and G passes
-#define BR_ST(Y, i) ((Y).st[0] + (i) * 2 * (Y).SU)
+#define BR_ST(Y, i) ((Y).st[0] + (i) * (Y).stw)
 // lanes per barcode of a loglambda segment: one per pair of time points.  (Any count works: the moment contributions are summed
 // by column walks over the segment's lanes, stride LPB, not by a butterfly over lane bits -- T = 6 used to idle one lane in four.)
 static inline int br_lpb(int T) { return (T + 1) / 2; }
@@ -112,7 +113,7 @@ static inline
 #ifndef BB_EMU
 __host__ __device__
 #endif
-BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf = false) {
+BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf = false, bool stream = false) {
     BRLay Y;
     const int X = (M.kind == 1) ? M.E : (M.kind == 4 ? M.E * M.R : M.R);
     const int KK = M.K + 2 * M.nt1;
@@ -124,12 +125,15 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf
     Y.NBT = 0;
     for (int r = 0; r < BB_MAX_REP; ++r) { Y.zr0[r] = Y.NBT; if (r < M.R) Y.NBT += NB * (M.T[r] + 1); }
     Y.NBT = (Y.NBT + 1) & ~1;
-    Y.zl = o;      o += 2 * Y.NBT;
+    Y.zlw = stream ? 1 : 2;          // (k_stream, bb_stream.h: single buffers -- a barrier ends its step)
+    Y.zl = o;      o += Y.zlw * Y.NBT;
     Y.SU = NB * X;
     Y.nst = M.kind <= 1 ? 3 : 6;
-    for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += 2 * Y.SU; }
+    Y.stw = Y.zlw * Y.SU;
+    for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += Y.stw; }
     o = (o + 1) & ~1;
     Y.rowmap = o;  o += M.K + 1;          // [K] int pairs
+    L.tmap = o;    o += (M.K + 1) / 2 + 1;
     L.wk = o;      o += KK;
     L.zgl = o;     o += 2 * M.nt1;
     L.Lt = o;      o += M.Ttot;
@@ -158,10 +162,15 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf
     int racc_total = 0;
     for (int r = 0; r < BB_MAX_REP; ++r) {
         Y.racc_r[r] = Y.racc + racc_total;
-        Y.rw[r] = r < M.R ? (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll) : 0;
+        // (k_stream: a thread adds its pair slots' contributions up in registers, the 16-lane rows of a wave reduce them by class, so a
+        //  column holds one entry per (row of 16 lanes, class) instead of one per lane of the segment)
+        Y.rw[r] = r < M.R ? (stream ? (NT / 16) * Y.lpb[r] : (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll)) : 0;
         if (r < M.R) racc_total += BR_NCV * (Y.rw[r] + 4);
     }
-    if (own_hbuf) {
+    if (stream) {
+        Y.hbuf = Y.eps = Y.racc;         // (neither exists: normals and window slots go through registers)
+        o += racc_total;
+    } else if (own_hbuf) {
         // the window slot is fetched while the moment contributions are alive (RunArgs.pf = 1, 2): a region of its own
         Y.eps = Y.racc;
         { const int need = racc_total > 2 * P * NT ? racc_total : 2 * P * NT; o += need; }
@@ -197,6 +206,8 @@ struct BRSt {
     unsigned cnt[P][2];                 // loglambda: the two counts
     bb_f4 lo[P];                        // low-order parts of the four running window sums (bb_opt_apply)
     bb_d2 gp[P];                        // loglambda pairs: the part of the gradient that needs no totals (br_grad_pre)
+    bb_d2 gm[P], go[P];                 // MS instances (several MC samples per step): running sums of d/dmu, d/domega over the samples
+    double el;                          // MS instances, recording steps: the thread's ELBO terms of the current sample
 };
 
 enum { BRM_A0 = 1 << 4, BRM_A1 = 1 << 5, BRM_VALID = 1 << 6, BRM_MUT = 1 << 7, BRM_PREV = 1 << 8, BRM_NEXT = 1 << 9 };
@@ -328,9 +339,91 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
     return n;
 }
 
-// ---- prologue: segment table, row map, per-thread metadata, state into registers --------------------------------
+// ---- what a thread knows about pair p of its tile's padded index space (segment, latent index, LDS offsets, counts): slot k of st ----
 template <int KIND, int P, bool AP = false>
-BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, BRSt<P>* stv) {
+BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int nseg, int g0, int g1, int p, BRSt<P>& st, int k) {
+    const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
+    int si = -1;
+    for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
+    int meta = 15;                          // (kind 15: no segment -- SK_L is 0)
+    long long i0 = 0;
+    st.zoff[k] = 0; st.uo[k][0] = st.uo[k][1] = st.uo[k][2] = 0; st.pt[k] = 0; st.cnt[k][0] = st.cnt[k][1] = 0u;
+    st.rb[k] = 0; st.thoff[k] = 0;
+    if (si >= 0) {
+        const BRSeg s = sg[si];
+        meta = s.kind | (si << 12);
+        if (s.kind == SK_L) {
+            const int q = p - s.tbeg, bl = q / s.lpb, kk = q - bl * s.lpb;
+            st.rb[k] = Y.racc_r[s.r] + q;           // (every lane of the segment's waves has a column entry; idle lanes write zeros)
+            if (2 * kk < s.T) {
+                const int t0 = 2 * kk;
+                i0 = s.lo + (long long)bl * s.T + t0;
+                meta |= BRM_A0 | (t0 + 1 < s.T ? BRM_A1 : 0) | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);   // (odd T: the last lane owns one latent)
+                st.zoff[k] = s.ldsoff + bl * (s.T + 1) + t0;
+                st.pt[k] = M.tcum[s.r] + t0;
+                if (bl >= t.nshift) {
+                    meta |= BRM_MUT;
+                    const int ml = bl - t.nshift;
+                    // stage index of the unit (ml [, r] [, e]) -- fitness: ml; multienv: ml E + e; replicate: r NB + ml;
+                    // multienv_replicate: (r NB + ml) E + e -- for the differences t0-1, t0, t0+1 (environment of t + 1)
+                    const int base = KIND >= 3 ? (s.r * t.NB + ml) * E : ml * E;
+                    // (genotype model: unit ml, theta index = its genotype's position among the tile's own = ml - thoff)
+                    st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : (KIND == 2 ? ml - (M.geno_idx[t.m0 + ml] - g0) : 0);
+                    for (int d = 0; d < 3; ++d) {
+                        const int tt = t0 - 1 + d;
+                        const int e = (E > 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
+                        st.uo[k][d] = base + e;
+                    }
+                }
+                const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
+                st.cnt[k][0] = M.counts[cb];
+                st.cnt[k][1] = t0 + 1 < s.T ? M.counts[cb + 1] : 0u;
+            }
+        } else {
+            const int q = p - s.tbeg;
+            i0 = 2 * ((s.lo >> 1) + q);
+            const bool a0 = i0 >= s.lo, a1 = i0 + 1 < s.hi;
+            meta |= (a0 ? BRM_A0 : 0) | (a1 ? BRM_A1 : 0) | BRM_VALID;
+            st.zoff[k] = s.ldsoff + (int)(i0 - s.lo);      // stage index of latent 0 (may sit one before the segment: never stored)
+            st.thoff[k] = s.ldsoff;                          // (hierarchical: r NB E_; the theta of unit j is j - thoff)
+            if (KIND == 2 && s.kind == SK_TH_R) {
+                // theta of genotype g: its mutants are the consecutive local units [first, first + n) -- uo[x] = first | n << 16
+                for (int x = 0; x < 2; ++x) {
+                    const long long g = g0 + (i0 - s.lo) + x;
+                    int first = 0, n = 0;
+                    if (g >= g0 && g < g1) {
+                        n = M.geno_ptr[g + 1] - M.geno_ptr[g];
+                        if (n > 0) first = (int)(M.geno_mem[M.geno_ptr[g]] - t.m0);
+                    }
+                    st.uo[k][x] = first | (n << 16);
+                }
+            } else if (s.kind < SK_GS) {
+                // unit (ml, e) of latent x: index j = (i0 - lo) + x = ml * E + e inside the segment; its barcode's local index
+                int env = 0;
+                for (int x = 0; x < 2; ++x) {
+                    int j = (int)(i0 - s.lo) + x;
+                    if (j < 0) j = 0;
+                    const int ml = j / E, e = j - ml * E;
+                    st.uo[k][x] = t.nshift + ml;
+                    // (genotype model, E == 1: the unit's theta index instead of its environment, 16 bits each)
+                    if (KIND == 2) env |= ((j < t.nmt ? M.geno_idx[t.m0 + j] - g0 : 0) & 0xffff) << (16 * x);
+                    else env |= e << (8 * x);
+                }
+                st.uo[k][2] = env;
+                st.pt[k] = s.r;
+            }
+        }
+    }
+    st.i0[k] = i0;
+    st.meta[k] = meta;
+}
+
+// ---- prologue: segment table, row map, per-thread metadata, state into registers --------------------------------
+// ---- tile setup shared by k_res and k_stream: segment table, zeroed LDS tables, row map, F-pass table (ends inside a pass: the caller
+// meets at a barrier before anything reads them).  ncol: column entries per time-pair class in the transposed contributions
+// (k_res: the tile's barcodes; k_stream: the rows of 16 lanes)
+template <int KIND>
+BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int ncol_or_neg) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
@@ -340,10 +433,10 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
     const int KK = M.K + 2 * M.nt1;
     BB_PASS(cx, tid) {
         // li[1] = exchange ok word; it starts at 0 ("leave") while an earlier launch's timeout is unacknowledged by the host
-        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0, g0, g1); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = t.nbt; }
+        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0, g0, g1); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = ncol_or_neg < 0 ? t.nbt : ncol_or_neg; }
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
-        for (int i = tid; i < 2 * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
-        for (int i = tid; i < 2 * Y.nst * Y.SU; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
+        for (int i = tid; i < Y.zlw * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
+        for (int i = tid; i < Y.nst * Y.stw; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
         if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
         if (tid < M.Ttot) ((int*)(lds + Y.envt))[tid] = (KIND == 1 || KIND == 4) ? M.env_idx[tid] : 0;
     }
@@ -366,6 +459,9 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             }
             rm[2 * j] = code;
             rm[2 * j + 1] = col;
+            int tj = -1;
+            for (int r = 0; r < M.R; ++r) { const int tt = j - M.kq[r]; if (tt >= 0 && tt < M.T[r]) tj = M.tcum[r] + tt; }
+            ((int*)(lds + L.tmap))[j] = tj;
         }
         // F-pass table: a lane of the F pass looked its replicate up in the model record -- a chain of four dependent vector loads from
         // device memory (~2 k cycles) in a pass the whole tile waits for
@@ -379,84 +475,26 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             ft[2] = tt > 0 ? 1 : 0;
             ft[3] = 0;
         }
+    }
+}
+
+template <int KIND, int P, bool AP = false>
+BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, BRSt<P>* stv) {
+    double* lds = cx.lds;
+    const BBLds& L = Y.L;
+    const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
+    const int g0 = KIND == 2 ? S.tile_g[cx.block] : 0, g1 = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
+    const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
+    const int* li = (const int*)(lds + L.misc);
+    br_tile_setup<KIND>(cx, M, S, A, Y, NB, -1);
+    BB_PASS(cx, tid) {
+        const int nseg = li[0];
         BRSt<P>& st = BB_PSTATE(stv, tid);
-        const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const int p = tid + k * cx.nthr;
-            int si = -1;
-            for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
-            int meta = 15;                          // (kind 15: no segment -- SK_L is 0)
-            long long i0 = 0;
-            st.zoff[k] = 0; st.uo[k][0] = st.uo[k][1] = st.uo[k][2] = 0; st.pt[k] = 0; st.cnt[k][0] = st.cnt[k][1] = 0u;
-            st.rb[k] = 0; st.thoff[k] = 0;
-            if (si >= 0) {
-                const BRSeg s = sg[si];
-                meta = s.kind | (si << 12);
-                if (s.kind == SK_L) {
-                    const int q = p - s.tbeg, bl = q / s.lpb, kk = q - bl * s.lpb;
-                    st.rb[k] = Y.racc_r[s.r] + q;           // (every lane of the segment's waves has a column entry; idle lanes write zeros)
-                    if (2 * kk < s.T) {
-                        const int t0 = 2 * kk;
-                        i0 = s.lo + (long long)bl * s.T + t0;
-                        meta |= BRM_A0 | (t0 + 1 < s.T ? BRM_A1 : 0) | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);   // (odd T: the last lane owns one latent)
-                        st.zoff[k] = s.ldsoff + bl * (s.T + 1) + t0;
-                        st.pt[k] = M.tcum[s.r] + t0;
-                        if (bl >= t.nshift) {
-                            meta |= BRM_MUT;
-                            const int ml = bl - t.nshift;
-                            // stage index of the unit (ml [, r] [, e]) -- fitness: ml; multienv: ml E + e; replicate: r NB + ml;
-                            // multienv_replicate: (r NB + ml) E + e -- for the differences t0-1, t0, t0+1 (environment of t + 1)
-                            const int base = KIND >= 3 ? (s.r * t.NB + ml) * E : ml * E;
-                            // (genotype model: unit ml, theta index = its genotype's position among the tile's own = ml - thoff)
-                            st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : (KIND == 2 ? ml - (M.geno_idx[t.m0 + ml] - g0) : 0);
-                            for (int d = 0; d < 3; ++d) {
-                                const int tt = t0 - 1 + d;
-                                const int e = (E > 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
-                                st.uo[k][d] = base + e;
-                            }
-                        }
-                        const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
-                        st.cnt[k][0] = M.counts[cb];
-                        st.cnt[k][1] = t0 + 1 < s.T ? M.counts[cb + 1] : 0u;
-                    }
-                } else {
-                    const int q = p - s.tbeg;
-                    i0 = 2 * ((s.lo >> 1) + q);
-                    const bool a0 = i0 >= s.lo, a1 = i0 + 1 < s.hi;
-                    meta |= (a0 ? BRM_A0 : 0) | (a1 ? BRM_A1 : 0) | BRM_VALID;
-                    st.zoff[k] = s.ldsoff + (int)(i0 - s.lo);      // stage index of latent 0 (may sit one before the segment: never stored)
-                    st.thoff[k] = s.ldsoff;                          // (hierarchical: r NB E_; the theta of unit j is j - thoff)
-                    if (KIND == 2 && s.kind == SK_TH_R) {
-                        // theta of genotype g: its mutants are the consecutive local units [first, first + n) -- uo[x] = first | n << 16
-                        for (int x = 0; x < 2; ++x) {
-                            const long long g = g0 + (i0 - s.lo) + x;
-                            int first = 0, n = 0;
-                            if (g >= g0 && g < g1) {
-                                n = M.geno_ptr[g + 1] - M.geno_ptr[g];
-                                if (n > 0) first = (int)(M.geno_mem[M.geno_ptr[g]] - t.m0);
-                            }
-                            st.uo[k][x] = first | (n << 16);
-                        }
-                    } else if (s.kind < SK_GS) {
-                        // unit (ml, e) of latent x: index j = (i0 - lo) + x = ml * E + e inside the segment; its barcode's local index
-                        int env = 0;
-                        for (int x = 0; x < 2; ++x) {
-                            int j = (int)(i0 - s.lo) + x;
-                            if (j < 0) j = 0;
-                            const int ml = j / E, e = j - ml * E;
-                            st.uo[k][x] = t.nshift + ml;
-                            // (genotype model, E == 1: the unit's theta index instead of its environment, 16 bits each)
-                            if (KIND == 2) env |= ((j < t.nmt ? M.geno_idx[t.m0 + j] - g0 : 0) & 0xffff) << (16 * x);
-                            else env |= e << (8 * x);
-                        }
-                        st.uo[k][2] = env;
-                        st.pt[k] = s.r;
-                    }
-                }
-            }
-            st.i0[k] = i0;
-            st.meta[k] = meta;
+            br_desc<KIND, P, AP>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, st, k);
+            const long long i0 = st.i0[k];
+            const int meta = st.meta[k];
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
             st.mu[k] = br_load_pair<AP>(S.mu, i0, a0, a1);
             st.om[k] = br_load_pair<AP>(S.om, i0, a0, a1);
@@ -478,7 +516,7 @@ static inline
 #else
 __device__ __attribute__((noinline))
 #endif
-void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsigned step, BRIdx<P> ix) {
+void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsigned step, unsigned stream, BRIdx<P> ix) {
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         if (!(ix.meta[k] & BRM_VALID)) continue;
@@ -491,7 +529,7 @@ void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsign
 #pragma nounroll
         for (int rep = 0; rep < (odd ? 2 : 1); ++rep) {
             double a, b;
-            bb_normal_pair(seed, (unsigned long long)(ix.i0[k] >> 1) + (unsigned long long)rep, step, 0u, &a, &b);
+            bb_normal_pair(seed, (unsigned long long)(ix.i0[k] >> 1) + (unsigned long long)rep, step, stream, &a, &b);
             if (rep == 0) { e0 = odd ? b : a; e1 = b; }
             else e1 = a;
         }
@@ -500,14 +538,14 @@ void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsign
 }
 
 template <int KIND, int P, bool AP = false>
-BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step) {
+BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step, unsigned stream = 0u) {
     bb_d2* eps = (bb_d2*)(cx.lds + Y.eps);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
         BRIdx<P> ix;
 #pragma unroll
         for (int k = 0; k < P; ++k) { ix.i0[k] = st.i0[k]; ix.meta[k] = st.meta[k]; }
-        br_draw_call<P, AP>(eps, cx.nthr, tid, A.seed, (unsigned)step, ix);
+        br_draw_call<P, AP>(eps, cx.nthr, tid, A.seed, (unsigned)step, stream, ix);
     }
 }
 
@@ -533,13 +571,19 @@ BB_DEV void br_unit_sw(const double* lds, const BRLay& Y, int buf, int o, int th
 // the slots' chains; only the stores depend on what the pair is.
 template <int P>
 BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int slot);
-template <int KIND, int P>
-BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf, int slot) {
+template <int KIND, int P> BB_DEV void br_pair_prior(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, bool a0, bool a1, double* pm0, double* iv0, double* pm1, double* iv1);
+// MS (instances that take several MC samples per step and record the ELBO): want_el -- this sample's ELBO terms are gathered
+//   per latent      -(z - m)^2 / (2 v^2) + log sigma            (prior quadratic + entropy term; bb_sample_pair)
+//   per (b, t)      R z - lambda                                  (Poisson; bb_pass_moments)
+//   per unit        - logsigma_eff x (time steps that use it)      (normaliser of the fitness likelihood; bb_effective_tables)
+// into BRSt.el; br_moments sums them over the tile (row entry K - 2), br_finish adds the per-time terms and stores the estimate.
+template <int KIND, int P, bool MS = false>
+BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf, int slot, bool prefetch = true, bool want_el = false) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     BB_STAMP(cx, S, 20);
     BB_STAMP_WAVE(cx, S, A, 1);
-    if (A.pf == 1) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
+    if (A.pf == 1 && prefetch) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
@@ -557,12 +601,47 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             st.z[k] = bb_d2{fma(sp0, e.x, st.mu[k].x), fma(sp1, e.y, st.mu[k].y)};
             st.a[k] = bb_d2{e.x * sg0, e.y * sg1};
             st.h[k] = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
+            if (MS && want_el) {
+                if (k == 0) st.el = 0.0;
+                const int meta = st.meta[k], kd = meta & 15;
+                const bool counted = (meta & BRM_VALID) && (kd < SK_GS || A.count_globals);      // (sharded run: rank 0 counts the replicated blocks)
+                if (counted) {
+                    const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+                    double pm0, iv0, pm1, iv1;
+                    br_pair_prior<KIND>(lds, Y, st, k, a0, a1, &pm0, &iv0, &pm1, &iv1);
+                    if (a0) st.el += -0.5 * (st.z[k].x - pm0) * (st.z[k].x - pm0) * iv0 + bb_log(sp0);
+                    if (a1) st.el += -0.5 * (st.z[k].y - pm1) * (st.z[k].y - pm1) * iv1 + bb_log(sp1);
+                }
+            }
             BR_SCHED_FENCE();
             // loglambda: lambda = e^z; logsigma_bc: precision w = e^{-2 z}; (others: unused)
             const int kd = st.meta[k] & 15;
             const double f = (kd == SK_LS_E || (KIND >= 2 && kd == SK_LS_R)) ? -2.0 : 1.0;      // logtau: e^{logtau}
             st.lam[k] = bb_d2{bb_exp(f * st.z[k].x), bb_exp(f * st.z[k].y)};
             BR_SCHED_FENCE();
+            if (MS && want_el && (st.meta[k] & BRM_VALID)) {
+                const int meta = st.meta[k];
+                if (kd == SK_L) {
+                    st.el += (double)st.cnt[k][0] * st.z[k].x - st.lam[k].x;
+                    if (meta & BRM_A1) st.el += (double)st.cnt[k][1] * st.z[k].y - st.lam[k].y;
+                } else if (kd == SK_LS_E || (KIND >= 2 && kd == SK_LS_R)) {
+                    // the unit's log sigma, once per time step that uses the unit (multienv kinds: the steps INTO its environment)
+                    const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
+                    const int T1 = sgk->T - 1;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        if (!(meta & (x ? BRM_A1 : BRM_A0))) continue;
+                        int n = T1;
+                        if (KIND == 1 || KIND == 4) {
+                            const int* envt = (const int*)(lds + Y.envt);
+                            const int e_ = (st.uo[k][2] >> (8 * x)) & 255, tc = KIND == 4 ? M.tcum[st.pt[k]] : 0;
+                            n = 0;
+                            for (int tt = 0; tt < T1; ++tt) n += envt[tc + tt + 1] == e_ ? 1 : 0;
+                        }
+                        st.el -= (x ? st.z[k].y : st.z[k].x) * (double)n;
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -620,9 +699,26 @@ __device__ __forceinline__ double br_row16_sum(double s) {
 // ---- M: the pairs' differences and moment contributions, summed in the thread over its pair slots (they share the time pair),
 // transposed into LDS; after the barrier 16 lanes per row entry walk their column and a DPP row sum finishes the entry, which
 // goes straight to the tile's published row ------------------------------------------------------------------------------------
-template <int KIND, int P, bool TG = false>
-BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch) {
+template <int KIND, int P, bool TG = false, bool MS = false>
+BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch, bool want_el = false) {
     double* lds = cx.lds;
+    if (MS && want_el) {
+        // the threads' ELBO terms: summed per wave (DPP rows, then the four rows in order), one partial per wave in LDS; the row
+        // pass below adds the waves in order -> row entry K - 2
+        BB_PASS(cx, tid) {
+            BRSt<P>& st = BB_PSTATE(stv, tid);
+#ifdef BB_EMU
+            (void)st;                                  // (emulation: summed thread by thread below)
+#else
+            double e = br_row16_sum(st.el);
+            const int lo = __double2loint(e), hi = __double2hiint(e);
+            double w = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+            if ((tid & 63) == 0) lds[Y.L.part + (tid >> 6)] = w;
+#endif
+        }
+    }
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
@@ -668,7 +764,21 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
     const int nbt = ((const int*)(lds + Y.L.misc))[2];          // barcodes of this tile: column entries per time-pair class
     BB_PASS(cx, tid) {
         const int c = tid & 15;
+        if (MS && tid == 0) {
+            double e = 0.0;
+            if (want_el) {
+#ifdef BB_EMU
+                for (int t2 = 0; t2 < cx.nthr; ++t2) e += BB_PSTATE(stv, t2).el;
+#else
+                for (int w = 0; w < (cx.nthr >> 6); ++w) e += lds[Y.L.part + w];
+#endif
+            }
+            if (TG && BR_PUB_COALESCED) lds[Y.L.wk + M.K - 2] = e;
+            else if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + M.K - 2, e, epoch);
+            else bb_st<true>(S.prow + (long long)cx.block * KK + M.K - 2, e);
+        }
         for (int j = tid >> 4; j < M.K; j += cx.nthr >> 4) {
+            if (MS && j == M.K - 2) continue;
             const int code = rm[2 * j], lpb = code & 255;
             const double* col = lds + rm[2 * j + 1];
             double s = 0.0;
@@ -740,8 +850,8 @@ BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, co
 }
 
 // ---- F: everything that depends only on the totals (tiny; ends with barrier 3) --------------------------------------------
-template <int KIND>
-BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y) {
+template <int KIND, bool MS = false>
+BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, const RunArgs* Ap = nullptr, bool want_el = false, int ring = 0, int smp = 0) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     BB_STAMP(cx, S, 25);
@@ -762,7 +872,11 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
                 Dt = (M1 - c * M0) + wb * (N1 - c * nn);
                 lds[L.gglob + zo] = -Dt;
                 lds[L.gglob + M.nt1 + zo] = wb * quadN - nn;
-            }
+                if (MS && want_el) {
+                    const double M2 = mm[2], quadM = M2 - 2.0 * c * M1 + c * c * M0;
+                    lds[L.elbt + j] = -0.5 * (quadM + wb * quadN) - nn * ls;
+                }
+            } else if (MS && want_el) lds[L.elbt + j] = 0.0;
             lds[L.cc + j] = c;
             lds[L.wbar + j] = wb;
             lds[L.Dt + j] = Dt;
@@ -774,6 +888,18 @@ BB_DEV void br_finish(BBCtx& cx, const DevModel& M, const DevState& S, const BRL
     }
     BB_SYNC(cx);                     // barrier 3
     BB_STAMP(cx, S, 26);
+    if (MS && want_el && cx.block == 0) {
+        // ELBO estimate of this sample (bb_block_update): tile and theta-block terms came back with the totals (row entries K - 2, K - 1)
+        BB_PASS(cx, tid) {
+            if (tid == 0) {
+                const RunArgs& A = *Ap;
+                double v = lds[L.wk + M.K - 2] + lds[L.wk + M.K - 1] + A.elbo_const;
+                for (int j = 0; j < M.Ttot; ++j) v += lds[L.elbt + j];
+                double* slot = S.elbo_ring + ring;
+                *slot = (smp == 0 ? 0.0 : *slot) + v / (double)A.S;
+            }
+        }
+    }
 }
 
 // ---- G: gradients from registers, prior, optimiser, window slot -----------------------------------------------------------
@@ -884,9 +1010,11 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
 // TT > 0: the number of time points is a compile-time constant -- the unit threads then fetch their barcodes' whole rows at once
 // (with the row walk as a runtime loop, one LDS round trip per time step, the unit waves' G pass took 13 k cycles against 4 k
 // for the loglambda waves and the whole tile waited for them).
-template <int KIND, int P, int TT = 0, bool AP = false>
+// MS instances, NS > 1 MC samples per step (AdvancedVI's ELBO estimator, Turing.ADVI(samples_per_step, ..), src/vi.jl:98): sample smp's
+// gradient joins running sums; the last sample averages them, adds the entropy term and updates -- the arithmetic of bb_update_pair.
+template <int KIND, int P, int TT = 0, bool AP = false, bool MS = false>
 BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
-                      const BBSlot wslot, int buf, int NBs) {
+                      const BBSlot wslot, int buf, int NBs, int smp = 0, int NS = 1) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     // (Measured and dropped: letting a barcode's loglambda lanes also form its units' sums As, Qs -- a DPP sum over the LPB lanes,
@@ -996,7 +1124,15 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             }
             g0 -= (z0 - pm0) * iv0;
             g1 -= (z1 - pm1) * iv1;
-            const double go0 = fma(g0, st.a[k].x, st.h[k].x), go1 = fma(g1, st.a[k].y, st.h[k].y);
+            double go0, go1;
+            if (MS && NS > 1) {
+                go0 = g0 * st.a[k].x; go1 = g1 * st.a[k].y;
+                if (smp > 0) { g0 += st.gm[k].x; g1 += st.gm[k].y; go0 += st.go[k].x; go1 += st.go[k].y; }
+                if (smp < NS - 1) { st.gm[k] = bb_d2{g0, g1}; st.go[k] = bb_d2{go0, go1}; continue; }
+                const double invS = 1.0 / (double)NS;
+                g0 *= invS; g1 *= invS;
+                go0 = go0 * invS + st.h[k].x; go1 = go1 * invS + st.h[k].y;
+            } else { go0 = fma(g0, st.a[k].x, st.h[k].x); go1 = fma(g1, st.a[k].y, st.h[k].y); }
             bb_d2 hm{0, 0}, ho{0, 0};
             if (hs_m) {
 #ifndef BB_EMU
@@ -1055,35 +1191,40 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 }
 
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
+// `xc` numbers the exchanges of a handle's life: the step, or step x S + sample in the instances that take several samples per
+// step; it gives the parity of the double-buffered tables and rows and the rows' epoch.
 template <int KIND, int P, bool AP = false>
-BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long step, int slot) {
+BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long xc, int slot,
+                            unsigned long long next_step, unsigned next_stream = 0u, bool prefetch = true) {
     // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
-    if (A.pf == 0) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
-    br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(step & 1));          // what of this step's gradient needs no totals
-    br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, step + 1);         // the next step's normals, in the shadow of the rows' flight
+    if (A.pf == 0 && prefetch) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
+    br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(xc & 1));          // what of this step's gradient needs no totals
+    br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, next_step, next_stream);         // the next normals, in the shadow of the rows' flight
 }
 template <bool XG>
-BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, unsigned long long step, int* ok_slot) {
-    const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
+BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, unsigned long long xc, int* ok_slot) {
+    const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
     // (fetching the members' rows in one round trip -- two waves, 16 members each, partial sums through LDS -- measured SLOWER,
     //  as round 1 had found for k_persist: 7.6 k cycles against 4.8 k for the leader's read + sum + publish)
     if (cx.block < bbp_groups(A)) {
-        if (!XG && BR_TG) bbp_leader_reduce_tg(cx, M, S, A, (int)(step & 1), epoch, ok_slot);
-        else bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
+        if (!XG && BR_TG) bbp_leader_reduce_tg(cx, M, S, A, (int)(xc & 1), epoch, ok_slot);
+        else bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
     }
 }
-template <int KIND, int P, bool XG>
+template <int KIND, int P, bool XG, bool MS = false>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
-                            unsigned long long step, int* ok_slot) {
-    const unsigned epoch = A.xepoch0 + (unsigned)(step + 1);
-    if (!XG && BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot);
-    else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(step & 1), epoch, ok_slot, epoch);
-    br_finish<KIND>(cx, M, S, Y);
+                            unsigned long long xc, int* ok_slot, bool want_el = false, int ring = 0, int smp = 0) {
+    const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
+    if (!XG && BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
+    else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
+    br_finish<KIND, MS>(cx, M, S, Y, &A, want_el, ring, smp);
 }
 
 #ifndef BB_EMU
-template <int KIND, int P, int NT, bool XG = false, int TT = 0, bool AP = false>
+// MS = false: one MC sample per step, no ELBO recording (the lean instances every BASELINE shape runs).  MS = true: A.S >= 1 samples
+// per step (each with its own exchange) and, every A.elbo_every steps, the ELBO estimate into the ring.
+template <int KIND, int P, int NT, bool XG = false, int TT = 0, bool AP = false, bool MS = false>
 __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, const BRLay* __restrict__ Yp,
                                             RunArgs A, int NB, int nsteps) {
     const DevModel& M = *Mp;
@@ -1107,26 +1248,41 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
         BB_STAMP_RT(cx, S, 4);
         BBSlotCtr sc = bb_slot_init(A, step0);
         if (A.pf == 2) br_prefetch_slot<P>(cx, M, S, A, Y, &st, sc.slot);
+        const int NS = MS ? A.S : 1;
+        // ELBO recording (MS): position inside the recording period and the ring slot, carried like the window slot
+        int ec = (MS && A.elbo_every > 0) ? bb_uniform((int)(step0 % (unsigned long long)A.elbo_every)) : 1;
+        int ring = (MS && A.elbo_every > 0) ? bb_uniform((int)(((step0 + (unsigned long long)A.elbo_every - 1ull) / (unsigned long long)A.elbo_every) % BB_ELBO_RING)) : 0;      // (of the next recording step)
         for (; done < nsteps; ++done, bb_slot_next(A, sc)) {
             const unsigned long long step = step0 + (unsigned long long)done;
             const BBSlot wslot = bb_slot_now(A, sc);
-            const int buf = (int)(step & 1);
-            // Several pair slots: the pair descriptors are opaque to the compiler at every step.  Otherwise it hoists the ~15
-            // predicates on each of them (kind, valid, mutant, has neighbour ...) out of the step loop as 64-bit lane masks --
-            // scalar registers the loop does not have, so that they lived in VGPR lanes (two v_readlane_b32 per use) and took
-            // vector registers from the pair state: C3's instance 58 -> 9 spilled registers, 22.4 -> 20.1 us per step.  (One
-            // slot of the fitness / multienv kinds: no gain, -0.4 %.)
-            if (P > 1 || KIND >= 2) {
+            const bool want_el = MS && A.elbo_every > 0 && ec == 0;
+            bool stop = false;
+            for (int smp = 0; smp < NS; ++smp) {
+                const unsigned long long xc = MS ? step * (unsigned long long)NS + (unsigned long long)smp : step;
+                const int buf = (int)(xc & 1);
+                const bool last = smp == NS - 1;
+                // Several pair slots: the pair descriptors are opaque to the compiler at every step.  Otherwise it hoists the ~15
+                // predicates on each of them (kind, valid, mutant, has neighbour ...) out of the step loop as 64-bit lane masks --
+                // scalar registers the loop does not have, so that they lived in VGPR lanes (two v_readlane_b32 per use) and took
+                // vector registers from the pair state: C3's instance 58 -> 9 spilled registers, 22.4 -> 20.1 us per step.  (One
+                // slot of the fitness / multienv kinds: no gain, -0.4 %.)
+                if (P > 1 || KIND >= 2) {
 #pragma unroll
-                for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
+                    for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
+                }
+                br_sample<KIND, P, MS>(cx, M, S, A, Y, &st, buf, wslot.slot, last, want_el);
+                br_moments<KIND, P, !XG && BR_TG, MS>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(xc + 1), want_el);
+                br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
+                br_xchg_lead<XG>(cx, M, S, A, Y, xc, ok_slot);
+                br_xchg_consume<KIND, P, XG, MS>(cx, M, S, A, Y, &st, xc, ok_slot, want_el, ring, smp);
+                if (*ok_slot == 0) { stop = true; break; }                 // uniform: read after barrier 3
+                br_update<KIND, P, TT, AP, MS>(cx, M, S, A, Y, &st, wslot, buf, NB, smp, NS);
             }
-            br_sample<KIND, P>(cx, M, S, A, Y, &st, buf, wslot.slot);
-            br_moments<KIND, P, !XG && BR_TG>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, step, wslot.slot);
-            br_xchg_lead<XG>(cx, M, S, A, Y, step, ok_slot);
-            br_xchg_consume<KIND, P, XG>(cx, M, S, A, Y, &st, step, ok_slot);
-            if (*ok_slot == 0) break;                                  // uniform: read after barrier 3
-            br_update<KIND, P, TT, AP>(cx, M, S, A, Y, &st, wslot, buf, NB);
+            if (stop) break;
+            if (MS && A.elbo_every > 0) {
+                if (ec == 0) ring = ring + 1 == BB_ELBO_RING ? 0 : ring + 1;
+                ec = ec + 1 == A.elbo_every ? 0 : ec + 1;
+            }
         }
     }
     BB_STAMP_RT(cx, S, 5);

@@ -126,22 +126,26 @@ def _trajectory(lib, sp, nsteps, S, optname, seed=11, use_priors=False, **ekw):
     return e, np.abs(mu - m2).max(), np.abs(om - o2).max(), tr
 
 
-def case_trajectory_exact(lib, name, optname, S, tol=1e-10):
+def case_trajectory_exact(lib, name, optname, S, tol=1e-10, **ekw):
     """resum_every=1: the window is re-added every step, the reference's own arithmetic."""
     sp = synth(name, seed=2)
-    e, a, b, _ = _trajectory(lib, sp, 12, S, optname, window=5, resum_every=1)
+    e, a, b, _ = _trajectory(lib, sp, 12, S, optname, window=5, resum_every=1, **ekw)
+    k = e.stats()["resident_kernel"]
     e.close()
     assert a < tol and b < tol, (a, b)
+    return k
 
 
-def case_trajectory_running(lib, name, graph=0):
+def case_trajectory_running(lib, name, graph=0, S=1, **ekw):
     """default running-window sum (exact re-add once per window) + ELBO trace."""
     sp = synth(name, seed=2)
-    e, a, b, tr = _trajectory(lib, sp, 23, 1, "TruncatedADAGrad", window=5, elbo_every=1, steps_per_graph=graph)
+    e, a, b, tr = _trajectory(lib, sp, 23, S, "TruncatedADAGrad", window=5, elbo_every=1, steps_per_graph=graph, **ekw)
     got = e.elbo_trace(0, 23)
+    k = e.stats()["resident_kernel"]
     e.close()
     assert a < 1e-6 and b < 1e-6, (a, b)
     assert np.abs(got - tr).max() <= 1e-6 * np.abs(tr).max()
+    return k
 
 
 def case_matrix_priors(lib):

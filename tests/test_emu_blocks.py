@@ -39,6 +39,18 @@ def test_matrix_priors(emu_lib):
     c.case_matrix_priors(emu_lib)
 
 
+@pytest.mark.parametrize("name", ["fitness_T6", "multienv_T8", "genotype_runs", "replicate_R3", "multienv_replicate_T6", "fitness_multi_tile"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_several_samples_and_elbo_trace_resident(emu_lib, name, mode):
+    """Turing.ADVI(samples_per_step, ..) with S = 2, 3 and the ELBO trace: launch_mode 2 = k_res's MS instances (every sample its own
+    exchange inside the one launch, gradients summed in registers, the ELBO from the reduced moments) against the literal oracle's
+    loop -- and launch_mode 1, the two-kernel step, against the same."""
+    assert c.case_trajectory_exact(emu_lib, name, "TruncatedADAGrad", 2, launch_mode=mode) == (2 if mode == 2 else 0)
+    assert c.case_trajectory_exact(emu_lib, name, "DecayedADAGrad", 3, launch_mode=mode) == (2 if mode == 2 else 0)
+    assert c.case_trajectory_running(emu_lib, name, S=2, launch_mode=mode) == (2 if mode == 2 else 0)
+    assert c.case_trajectory_running(emu_lib, name, S=1, launch_mode=mode) == (2 if mode == 2 else 0)
+
+
 @pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged", "multienv_replicate"])
 def test_sharded_split_phase(emu_lib, name):
     c.case_sharded_split_phase(emu_lib, name)
@@ -252,8 +264,12 @@ def test_persistent_two_pairs_per_thread(emu_lib, monkeypatch):
 def test_persistent_not_eligible_is_an_error(emu_lib):
     import barbay_jl_amd as bb
     from conftest import make_engine
+    # several samples per step run resident on k_res (its MS instances); where the shape has no k_res instance -- the ragged-method
+    # pairing -- the resident launch is refused
+    with make_engine(c.synth("multienv"), emu_lib, launch_mode=2, samples_per_step=2) as e:
+        assert e.stats()["resident_kernel"] == 2
     with pytest.raises(bb.BarBayHipError, match="samples_per_step"):
-        make_engine(c.synth("multienv"), emu_lib, launch_mode=2, samples_per_step=2)
+        make_engine(c.synth("replicate_ragged"), emu_lib, launch_mode=2, samples_per_step=2, ragged_method=True)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -372,7 +388,7 @@ def test_multi_device_handle_launch_mode_2(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NTHR", "256")
     c.case_multi_device_handle(emu_lib, "fitness_T6", 2, launch_mode=2)
     with pytest.raises(bb.BarBayHipError, match="launch_mode = 2"):
-        make_engine(c.synth("multienv"), emu_lib, device_ids=[0, 0], launch_mode=2, samples_per_step=2)
+        make_engine(c.synth("multienv"), emu_lib, device_ids=[0, 0], launch_mode=2, samples_per_step=2)      # (sharded: single-sample instances only)
 
 
 def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeypatch):

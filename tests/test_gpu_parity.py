@@ -39,6 +39,18 @@ def test_matrix_priors(hip_lib):
     c.case_matrix_priors(hip_lib)
 
 
+@pytest.mark.parametrize("name", ["fitness_T6", "multienv_T8", "genotype_runs", "replicate_R3", "multienv_replicate_T6", "fitness_multi_tile"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_several_samples_and_elbo_trace_resident(hip_lib, name, mode):
+    """Turing.ADVI(samples_per_step, ..) with S = 2, 3 and the ELBO trace: launch_mode 2 = k_res's MS instances (every sample its own
+    exchange inside the one launch, gradients summed in registers, the ELBO from the reduced moments) against the literal oracle's
+    loop -- and launch_mode 1, the two-kernel step, against the same."""
+    assert c.case_trajectory_exact(hip_lib, name, "TruncatedADAGrad", 2, launch_mode=mode) == (2 if mode == 2 else 0)
+    assert c.case_trajectory_exact(hip_lib, name, "DecayedADAGrad", 3, launch_mode=mode) == (2 if mode == 2 else 0)
+    assert c.case_trajectory_running(hip_lib, name, S=2, launch_mode=mode) == (2 if mode == 2 else 0)
+    assert c.case_trajectory_running(hip_lib, name, S=1, launch_mode=mode) == (2 if mode == 2 else 0)
+
+
 @pytest.mark.parametrize("name", ["fitness_multi_tile", "multienv", "replicate_ragged", "multienv_replicate"])
 def test_sharded_split_phase(hip_lib, name):
     c.case_sharded_split_phase(hip_lib, name)
