@@ -11,6 +11,7 @@
 #include "bb_block.h"
 #include "bb_persist.h"
 #include "bb_resident.h"
+#include "bb_stream.h"
 #include "bb_inst.h"
 #include "bb_hier.h"
 
@@ -263,6 +264,7 @@ struct bb_handle {
     int persist_P = 0;                 // pairs per thread of the persistent launch (0 = not eligible)
     int res_P = 0;                     // > 0: the launch is k_res (bb_resident.h, owner-computes) with this many pair slots per thread
     int res_pf = 0;                    // ... when it fetches a step's window slot (RunArgs.pf)
+    bool res_stream = false;           // ... the launch is k_stream (bb_stream.h): res_P pair slots per thread, state streamed from memory
     int res_NB = 0, res_NBL = 0, res_nblk = 0;   // ... its own tile map: barcodes per tile, per leader tile (0: uniform), tiles
     BRLay Yh{};                        // its LDS carve-up (host copy) and device copy
     BRLay* dY = nullptr;
@@ -425,6 +427,18 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool 
 }
 #endif
 
+#ifndef BB_EMU
+static bb_stream_kernel stream_kernel(int kind, int nthr, int T) {
+#ifdef BB_FAST_BUILD
+    if (nthr == 1024 && kind == 0 && T == 8) return k_stream<0, 1024, 8>;
+    if (nthr == 1024 && kind == 2 && T == 8) return k_stream<2, 1024, 8>;
+    return nullptr;
+#else
+    return bb_stream_instance(kind, nthr, T);
+#endif
+}
+#endif
+
 // pairs a tile can hold: every segment contributes count/2 + 1 at most
 static long long tile_pairs_bound(const DevModel& M, long long NB) {
     long long p = 0;
@@ -487,19 +501,23 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     if (!br_eligible(h->M)) return false;
     if (!any_parity && br_any_parity(h->M)) return false;
     // tile map: leaders (tiles 0 .. 7) hold `frac` of a tile's barcodes (br_tile); BB_TUNE_LEAD=100 keeps all tiles alike
-    int NB = h->NB, NBL = 0, nblk = h->nblk;
     const long long nbar = std::max<long long>(h->b_hi - h->b_lo, 1);
+    // The two-kernel step may run more tiles than the device has compute units (its tiles must fit LDS with ITS tables: config 5 on one
+    // GPU runs 512 of them); a resident launch needs every tile resident -- one per compute unit: its own base map then
+    int NB0 = h->NB, nblk0 = h->nblk;
+    if (nblk0 > h->cus && !getenv("BB_TUNE_NB")) { NB0 = (int)((nbar + h->cus - 1) / h->cus); nblk0 = (int)((nbar + NB0 - 1) / NB0); }
+    int NB = NB0, NBL = 0, nblk = nblk0;
     // groups of the exchange's first hop: 16 on one GPU where the grid is large and the tile has two thread groups for the consume
     // (bbp_consume<.., WIDE>); the cross-GPU inbox protocol is laid out for 8.  BB_TUNE_NG overrides (8 or 16).
     if (!h->p2p_on && h->M.K + 2 * h->M.nt1 > h->nthr) return false;      // (bbp_consume<.., WIDE>: one thread per row entry)
     {
         const int KK = h->M.K + 2 * h->M.nt1;
-        int ng = (!h->p2p_on && h->nblk >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)) ? 16 : 8;
+        int ng = (!h->p2p_on && nblk0 >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)) ? 16 : 8;
         if ((ev = getenv("BB_TUNE_NG")) && (atoi(ev) == 8 || (atoi(ev) == 16 && !h->p2p_on && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)))) ng = atoi(ev);
 #if BR_TG
         // self-validating rows: a leader takes its members' rows in batches of eight loads per lane -- 32 groups of 8 on a full grid:
         // one batch, one round trip (the tile's consume then runs on four thread groups)
-        if (ev && atoi(ev) == 32 && !h->p2p_on && h->nblk >= 64 && h->nthr >= 4 * ((KK + 63) & ~63)) ng = 32;
+        if (ev && atoi(ev) == 32 && !h->p2p_on && nblk0 >= 64 && h->nthr >= 4 * ((KK + 63) & ~63)) ng = 32;
 #endif
         h->res_ng = ng;
     }
@@ -508,23 +526,23 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     if (pct < 10 || pct > 100) pct = 100;
     const bool nb_fixed = getenv("BB_TUNE_NB") != nullptr;
     ev = getenv("BB_TUNE_LEAD");
-    if (pct < 100 && h->nblk >= 2 * NGh && (!nb_fixed || ev)) {
+    if (pct < 100 && nblk0 >= 2 * NGh && (!nb_fixed || ev)) {
         if (!nb_fixed) {
-            const double tiles = (double)h->nblk - (double)NGh * (1.0 - pct / 100.0);      // in units of a full tile
+            const double tiles = (double)nblk0 - (double)NGh * (1.0 - pct / 100.0);      // in units of a full tile
             NB = (int)std::ceil((double)nbar / tiles);
         }
         NBL = std::max(1, (int)(NB * (pct / 100.0)));
         const long long rest = nbar - (long long)NGh * NBL;
         nblk = NGh + (int)((std::max<long long>(rest, 0) + NB - 1) / NB);
-        const long long p_uni = (br_tile_span(h->M, h->NB, true) + h->nthr - 1) / h->nthr, p_new = (br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr;
+        const long long p_uni = (br_tile_span(h->M, NB0, true) + h->nthr - 1) / h->nthr, p_new = (br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr;
         // stay uniform where rounding pushed the map over the grid that fits, or the slightly larger tiles need another pair slot
-        if (nblk > h->nblk + (nb_fixed ? 8 : 0) || p_new > p_uni) { NB = h->NB; NBL = 0; nblk = h->nblk; }
+        if (nblk > nblk0 + (nb_fixed ? 8 : 0) || p_new > p_uni) { NB = NB0; NBL = 0; nblk = nblk0; }
     }
     std::vector<long long> tb;
     std::vector<int> tg;
     if (h->M.kind == BB_MODEL_GENOTYPE) {
         // cuts on genotype boundaries leave tiles partly empty: grow the tile until the map fits the grid again
-        const int limit = std::max(h->nblk, std::min(h->nblk + 8, h->cus));      // (the exchange buffers hold nblk + 8 tiles)
+        const int limit = std::max(nblk0, std::min(nblk0 + 8, h->cus));      // (the exchange buffers hold nblk + 8 tiles)
         bool ok = false;
         for (int grow = 0; grow <= NB / 2 + 8 && !ok; ++grow) {
             const int nb = NB + grow, nbl = NBL > 0 ? std::max(1, (int)((long long)NBL * nb / NB)) : 0;
@@ -536,24 +554,36 @@ static bool try_resident(bb_handle* h, bool any_parity) {
         if (h->p2p_on && nblk < 8) return false;
     }
     const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
-    if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
+    // more pair slots than the register file holds: k_stream (bb_stream.h) -- the same tile map, the per-pair state streamed
+    bool stream = false;
+    const bool force_stream = (ev = getenv("BB_TUNE_STREAM")) && atoi(ev) > 0;        // (tests: small shapes through k_stream)
+    if (force_stream || P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) {
+        const int T0 = h->M.T[0], lpb0 = br_lpb(T0);
+        const bool nostream = (ev = getenv("BB_NO_STREAM")) && atoi(ev) > 0;
+        stream = !nostream && h->M.R == 1 && h->M.kind <= 2 && !br_any_parity(h->M) && (T0 == 8 || T0 == 4) && 16 % lpb0 == 0 && h->nthr % 64 == 0 &&
+                 !h->p2p_on && h->o.samples_per_step == 1 && h->o.elbo_every == 0 && P <= 64;
+        if (!stream && !force_stream) return false;
+        if (!stream && P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
+    }
     // When the window slot is fetched (RunArgs.pf).  In the exchange's shadow (round 2) its 32 B per latent of HBM reads compete with
     // the exchange's own loads and stores: at the start of the S pass instead, C2 73.1 -> 77.7 k steps/s, C4 87.1 -> 89.1 k
     // (profiles/r03b_tagged_rows/prefetch_timing_on_lean_kernel.txt) -- where the slot buffer fits beside the moment contributions
     int pf = (ev = getenv("BB_TUNE_PF")) ? atoi(ev) : 1;
     if (pf < 0 || pf > 2 || h->o.optimizer != BB_OPT_TRUNCATED_ADAGRAD) pf = 0;
-    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, pf != 0);
+    if (stream) pf = 0;
+    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, pf != 0, stream);
     if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false); }
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
     const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
-    bb_res_kernel k = res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), ms);
+    const void* k = stream ? (const void*)stream_kernel(h->M.kind, h->nthr, uniform_T(h->M))
+                           : (const void*)res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), ms);
     if (!k) return false;
     const int lds = Y.total * 8;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
     int per_cu = 0;
     hipDeviceProp_t pr;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, h->nthr, (size_t)lds) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, h->nthr, (size_t)lds) != hipSuccess ||
         hipGetDeviceProperties(&pr, h->o.device) != hipSuccess || (long long)per_cu * pr.multiProcessorCount < nblk) return false;
 #endif
     if (h->M.kind == BB_MODEL_GENOTYPE) {
@@ -568,6 +598,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     h->res_NBL = NBL;
     h->res_nblk = nblk;
     h->res_pf = pf;
+    h->res_stream = stream;
     h->lds_doubles_p = (size_t)Y.total;
     return true;
 }
@@ -738,7 +769,48 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
     }
 }
 
+template <int KIND, int TT>
+static void emu_stream_phase(EmuPersist& E, int phase, long long it, long long nsteps) {
+    bb_handle* h = E.h;
+    const RunArgs& A = E.A;
+    BSAcc* acc = (BSAcc*)E.st.data();
+    auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), nullptr}; };
+    const BRLay& Y = h->Yh;
+    const unsigned long long step = (unsigned long long)(h->step + it);
+    BRSt<1>* nost = nullptr;
+    for (int b = 0; b < (phase == 2 ? bbp_groups(A) : h->res_nblk); ++b) {
+        BBCtx cx = cxof(b);
+        BSAcc* ab = acc + (size_t)b * h->nthr;
+        int* bad_any = (int*)(cx.lds + Y.L.misc) + 3;
+        if (phase == 0) {
+            br_tile_setup<KIND>(cx, h->M, h->S, A, Y, h->res_NB, h->nthr / 16);
+            *bad_any = 0;
+        } else if (phase == 1) {
+            bs_sample<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, ab);
+            bs_moments<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, ab);
+            br_row_publish<1, true, false>(cx, h->M, h->S, Y, nost, A.xepoch0 + (unsigned)(step + 1));
+        } else if (phase == 2) {
+            br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
+        } else if (phase == 3) {
+            br_xchg_consume<KIND, 1, false, false>(cx, h->M, h->S, A, Y, nost, step, &E.ok);
+            bs_update<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any);
+        } else {
+            if (*bad_any) h->S.hstatus[1] = 1u;
+            if (b == 0) { h->S.ctr[0] = (unsigned long long)(h->step + nsteps); h->S.ctr[1] = h->S.ctr[0]; }
+        }
+    }
+}
+
 static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long long nsteps) {
+    if (E.h->res_P && E.h->res_stream) {
+        const int T = uniform_T(E.h->M);
+        switch (E.h->M.kind) {
+        case 0: T == 8 ? emu_stream_phase<0, 8>(E, phase, it, nsteps) : emu_stream_phase<0, 4>(E, phase, it, nsteps); break;
+        case 1: T == 8 ? emu_stream_phase<1, 8>(E, phase, it, nsteps) : emu_stream_phase<1, 4>(E, phase, it, nsteps); break;
+        default: T == 8 ? emu_stream_phase<2, 8>(E, phase, it, nsteps) : emu_stream_phase<2, 4>(E, phase, it, nsteps);
+        }
+        return;
+    }
     if (E.h->res_P) {
         const bool ap = br_any_parity(E.h->M);
         auto byP = [&](auto kindc) {
@@ -791,7 +863,7 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
         es[i].A = make_args(h, h->step, 0, h->res_P ? h->o.samples_per_step : 1, true, false);
         if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; es[i].A.ng = h->res_ng; es[i].A.pf = h->res_pf; }
         es[i].lds.assign((size_t)std::max(h->nblk, h->res_nblk) * (h->lds_doubles_p + 64), 0.0);
-        es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P)), 0);
+        es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_stream ? sizeof(BSAcc) : (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P))), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
     }
     const long long NS = hs[0]->res_P ? std::max(hs[0]->o.samples_per_step, 1) : 1;
@@ -833,12 +905,14 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     // set leaves at once, so a queue of launches behind a timed-out one neither runs nor skips steps); every launch takes its
     // first step from the device counter.
     bb_persist_kernel k = h->res_P ? nullptr : persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on);
-    bb_res_kernel kr = h->res_P ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), res_ms(h)) : nullptr;
+    bb_res_kernel kr = (h->res_P && !h->res_stream) ? res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), res_ms(h)) : nullptr;
     if (h->res_P) { A.nblk = h->res_nblk; A.nbl = h->res_NBL; A.ng = h->res_ng; A.pf = h->res_pf; }
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
-        if (kr) hipLaunchKernelGGL(kr, dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n);
+        if (h->res_stream) hipLaunchKernelGGL(stream_kernel(h->M.kind, h->nthr, uniform_T(h->M)), dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream,
+                                              (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n, h->res_P);
+        else if (kr) hipLaunchKernelGGL(kr, dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n);
         else hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB, n);
         rc = launch_check();
         h->step += n;
@@ -2386,7 +2460,7 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->lds_bytes = (int32_t)((h->persist_P > 0 ? h->lds_doubles_p : h->lds_doubles) * 8);
     s->persistent_pairs = h->persist_P;
     s->launches_last_run = h->launches_last_run;
-    s->resident_kernel = h->res_P > 0 ? 2 : (h->persist_P > 0 ? 1 : 0);
+    s->resident_kernel = h->res_P > 0 ? (h->res_stream ? 3 : 2) : (h->persist_P > 0 ? 1 : 0);
     return BB_OK;
 }
 

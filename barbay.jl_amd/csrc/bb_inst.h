@@ -3,6 +3,7 @@
 // calls these functions.  (Experiment builds, -DBB_FAST_BUILD, keep a handful of instances inside bb_engine.hip itself.)
 #pragma once
 #include "bb_resident.h"
+#include "bb_stream.h"
 
 #ifndef BB_EMU
 typedef void (*bb_persist_kernel)(const DevModel*, const DevState*, const BBLds*, RunArgs, int, int);
@@ -16,4 +17,6 @@ BB_INST bb_res_kernel bb_res_instance_k1(int P, int nthr, bool xg, int T, bool a
 BB_INST bb_res_kernel bb_res_instance_k2(int P, int nthr, bool xg, int T, bool ap, bool ms);
 BB_INST bb_res_kernel bb_res_instance_k3(int P, int nthr, bool xg, int T, bool ap, bool ms);
 BB_INST bb_res_kernel bb_res_instance_k4(int P, int nthr, bool xg, int T, bool ap, bool ms);
+// k_stream<KIND, NT, TT>: kinds 0 .. 2, 1024 or 512 threads, T = 8 or 4
+BB_INST bb_stream_kernel bb_stream_instance(int kind, int nthr, int T);
 #endif

@@ -340,7 +340,9 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
 }
 
 // ---- what a thread knows about pair p of its tile's padded index space (segment, latent index, LDS offsets, counts): slot k of st ----
-template <int KIND, int P, bool AP = false>
+// (LPBC > 0: the lanes per barcode as a compile-time constant -- k_stream recomputes descriptors per pass and a run-time integer
+//  division costs ~30 instructions; CNT = false: the pair's counts are not fetched)
+template <int KIND, int P, bool AP = false, int LPBC = 0, bool CNT = true>
 BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int nseg, int g0, int g1, int p, BRSt<P>& st, int k) {
     const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
     int si = -1;
@@ -353,7 +355,7 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
         const BRSeg s = sg[si];
         meta = s.kind | (si << 12);
         if (s.kind == SK_L) {
-            const int q = p - s.tbeg, bl = q / s.lpb, kk = q - bl * s.lpb;
+            const int q = p - s.tbeg, bl = LPBC ? q / LPBC : q / s.lpb, kk = q - bl * (LPBC ? LPBC : s.lpb);
             st.rb[k] = Y.racc_r[s.r] + q;           // (every lane of the segment's waves has a column entry; idle lanes write zeros)
             if (2 * kk < s.T) {
                 const int t0 = 2 * kk;
@@ -375,9 +377,11 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
                         st.uo[k][d] = base + e;
                     }
                 }
-                const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
-                st.cnt[k][0] = M.counts[cb];
-                st.cnt[k][1] = t0 + 1 < s.T ? M.counts[cb + 1] : 0u;
+                if (CNT) {
+                    const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
+                    st.cnt[k][0] = M.counts[cb];
+                    st.cnt[k][1] = t0 + 1 < s.T ? M.counts[cb + 1] : 0u;
+                }
             }
         } else {
             const int q = p - s.tbeg;
@@ -699,65 +703,11 @@ __device__ __forceinline__ double br_row16_sum(double s) {
 // ---- M: the pairs' differences and moment contributions, summed in the thread over its pair slots (they share the time pair),
 // transposed into LDS; after the barrier 16 lanes per row entry walk their column and a DPP row sum finishes the entry, which
 // goes straight to the tile's published row ------------------------------------------------------------------------------------
-template <int KIND, int P, bool TG = false, bool MS = false>
-BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch, bool want_el = false) {
+// ---- the tile's row from the transposed contributions (after barrier 2): 16 lanes per row entry walk their column, a DPP row sum
+// finishes the entry; the row goes out (self-validating entries: from LDS as whole lines; else sc1 stores + drain + ready word) ----
+template <int P, bool TG = false, bool MS = false>
+BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, unsigned epoch, bool want_el = false) {
     double* lds = cx.lds;
-    if (MS && want_el) {
-        // the threads' ELBO terms: summed per wave (DPP rows, then the four rows in order), one partial per wave in LDS; the row
-        // pass below adds the waves in order -> row entry K - 2
-        BB_PASS(cx, tid) {
-            BRSt<P>& st = BB_PSTATE(stv, tid);
-#ifdef BB_EMU
-            (void)st;                                  // (emulation: summed thread by thread below)
-#else
-            double e = br_row16_sum(st.el);
-            const int lo = __double2loint(e), hi = __double2hiint(e);
-            double w = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
-            if ((tid & 63) == 0) lds[Y.L.part + (tid >> 6)] = w;
-#endif
-        }
-    }
-    BB_PASS(cx, tid) {
-        BRSt<P>& st = BB_PSTATE(stv, tid);
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const int meta = st.meta[k];
-            if ((meta & 15) != SK_L) continue;
-            double cv[BR_NCV];
-#pragma unroll
-            for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
-            if (meta & BRM_VALID) {
-            const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
-            const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
-            const double z0 = st.z[k].x, z1 = st.z[k].y;
-            const double zn = hn ? zb[2] : z1;
-            double dm = z1 - z0, dn = zn - z1;       // the pair's two forward differences (the backward one of z0 belongs to the previous pair)
-            cv[0] += st.lam[k].x;
-            cv[6] += st.lam[k].y;
-            if (mut) {
-                double sm, sn, wm, wn;
-                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &sm, &wm);
-                if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
-                else { sn = sm; wn = wm; }
-                dm -= sm; dn -= sn;
-                cv[1] += wm; cv[2] += wm * dm; cv[3] += wm * dm * dm;
-                if (hn) { cv[7] += wn; cv[8] += wn * dn; cv[9] += wn * dn * dn; }
-            } else {
-                cv[4] += dm; cv[5] += dm * dm;
-                if (hn) { cv[10] += dn; cv[11] += dn * dn; }
-            }
-            }
-            {   // (idle lanes of the segment write zeros: every column entry of its nbt * LPB lanes is fresh each step)
-                const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
-                const int stride = sgk->rstride;
-#pragma unroll
-                for (int q = 0; q < BR_NCV; ++q) lds[st.rb[k] + q * stride] = cv[q];
-            }
-        }
-    }
-    BB_SYNC(cx);                     // barrier 2: the contributions are in LDS
     BB_STAMP(cx, S, 23);
     const int KK = M.K + 2 * M.nt1;
     const int* rm = (const int*)(lds + Y.rowmap);
@@ -821,6 +771,68 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
     BB_STAMP(cx, S, 24);
     BB_STAMP_RT(cx, S, 29);
     BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
+}
+
+template <int KIND, int P, bool TG = false, bool MS = false>
+BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch, bool want_el = false) {
+    double* lds = cx.lds;
+    if (MS && want_el) {
+        // the threads' ELBO terms: summed per wave (DPP rows, then the four rows in order), one partial per wave in LDS; the row
+        // pass below adds the waves in order -> row entry K - 2
+        BB_PASS(cx, tid) {
+            BRSt<P>& st = BB_PSTATE(stv, tid);
+#ifdef BB_EMU
+            (void)st;                                  // (emulation: summed thread by thread below)
+#else
+            double e = br_row16_sum(st.el);
+            const int lo = __double2loint(e), hi = __double2hiint(e);
+            double w = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+            if ((tid & 63) == 0) lds[Y.L.part + (tid >> 6)] = w;
+#endif
+        }
+    }
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if ((meta & 15) != SK_L) continue;
+            double cv[BR_NCV];
+#pragma unroll
+            for (int q = 0; q < BR_NCV; ++q) cv[q] = 0.0;
+            if (meta & BRM_VALID) {
+            const double* zb = lds + Y.zl + buf * Y.NBT + st.zoff[k];
+            const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+            const double z0 = st.z[k].x, z1 = st.z[k].y;
+            const double zn = hn ? zb[2] : z1;
+            double dm = z1 - z0, dn = zn - z1;       // the pair's two forward differences (the backward one of z0 belongs to the previous pair)
+            cv[0] += st.lam[k].x;
+            cv[6] += st.lam[k].y;
+            if (mut) {
+                double sm, sn, wm, wn;
+                br_unit_sw<KIND>(lds, Y, buf, st.uo[k][1], KIND >= 2 ? st.thoff[k] : 0, &sm, &wm);
+                if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[k][2], KIND >= 3 ? st.thoff[k] : 0, &sn, &wn);
+                else { sn = sm; wn = wm; }
+                dm -= sm; dn -= sn;
+                cv[1] += wm; cv[2] += wm * dm; cv[3] += wm * dm * dm;
+                if (hn) { cv[7] += wn; cv[8] += wn * dn; cv[9] += wn * dn * dn; }
+            } else {
+                cv[4] += dm; cv[5] += dm * dm;
+                if (hn) { cv[10] += dn; cv[11] += dn * dn; }
+            }
+            }
+            {   // (idle lanes of the segment write zeros: every column entry of its nbt * LPB lanes is fresh each step)
+                const BRSeg* sgk = (const BRSeg*)(lds + Y.seg) + (meta >> 12);
+                const int stride = sgk->rstride;
+#pragma unroll
+                for (int q = 0; q < BR_NCV; ++q) lds[st.rb[k] + q * stride] = cv[q];
+            }
+        }
+    }
+    BB_SYNC(cx);                     // barrier 2: the contributions are in LDS
+    br_row_publish<P, TG, MS>(cx, M, S, Y, stv, epoch, want_el);
 }
 
 // ---- window-slot prefetch (in the exchange's shadow): LDS-DMA, 16 bytes per lane straight into LDS, no register held across the
@@ -970,13 +982,13 @@ BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
         }
     }
 }
-template <int KIND, int P, bool AP = false>
+template <int KIND, int P, bool AP = false, bool PRE = (P == 1 && KIND <= 1)>
 BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, int buf, double* g0, double* g1) {
     const BBLds& L = Y.L;
     const int meta = st.meta[k], pt = st.pt[k];
     const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT;
     const double cp = hp ? lds[L.cc + pt - 1] : 0.0, cm = lds[L.cc + pt], cn = hn ? lds[L.cc + pt + 1] : 0.0;
-    if (!br_has_pre<KIND, P>()) {    // everything here, after the totals
+    if (!PRE) {    // everything here, after the totals
         double pm0, iv0, pm1, iv1, z0, z1, ap, am, an, wp, wm, wn;
         br_pair_prior<KIND>(lds, Y, st, k, true, AP ? (st.meta[k] & BRM_A1) != 0 : true, &pm0, &iv0, &pm1, &iv1);
         br_pair_diffs<KIND>(lds, Y, st, k, buf, &z0, &z1, &ap, &am, &an, &wp, &wm, &wn);

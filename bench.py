@@ -199,7 +199,7 @@ def main():
         steps_per_launch = args.steps / launches
         launch_s = st["last_run_ms"] * 1e-3 / launches
         ach = st["bytes_per_step"] * steps_per_launch / launch_s / 1e9
-        kname = "k_res" if int(st.get("resident_kernel", 1)) == 2 else "k_persist"
+        kname = {1: "k_persist", 2: "k_res", 3: "k_stream"}.get(int(st.get("resident_kernel", 1)), "k_persist")
         nt = int(st["block_threads"])
         nt_inst = 1024 if nt > 512 else (512 if (nt > 256 or kname == "k_persist") else 256)
         roofline = {"bound": "hbm", "kernel": kname, "kernel_instance": f"{kname}<{bb._capi.BB_MODEL[wl.kind]}, {int(st['persistent_pairs'])}, {nt_inst}",

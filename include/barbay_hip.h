@@ -144,7 +144,8 @@ typedef struct bb_stats {
     int32_t persistent_pairs;  /* > 0: bb_run uses the resident launch with this many latent pairs per thread */
     int32_t launches_last_run; /* kernel launches of the last bb_run (resident launch: <= 4096 steps each)       */
     int32_t resident_kernel;   /* which resident launch bb_run uses: 0 none (two kernels per sample), 1 k_persist
-                                  (LDS-staged passes), 2 k_res (the owner of a latent computes; bb_resident.h)     */
+                                  (LDS-staged passes), 2 k_res (the owner of a latent computes; bb_resident.h), 3 k_stream
+                                  (k_res's tile map with the per-pair state streamed: tiles beyond the register file; bb_stream.h) */
     int32_t geno_lo, geno_hi;  /* genotype model: the genotypes whose theta THIS handle owns (0 .. n_geno unless the run is
                                   sharded and geno_idx is non-decreasing: shards are then cut at genotype boundaries, and after
                                   a resident run only the owner's copy of theta_g is current)                          */

@@ -130,6 +130,19 @@ def test_owner_computes_launch_sixteen_groups(emu_lib, monkeypatch, name, nb, nt
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name,nb,nthr", [("fitness_neutral_heavy", 64, 64), ("fitness_neutral_heavy", 140, 128), ("multienv_T8", 40, 64),
+                                          ("genotype_T8", 100, 128), ("genotype_T8", 130, 64), ("fitness_T4", 100, 64)])
+def test_streaming_resident_launch(emu_lib, monkeypatch, name, nb, nthr):
+    """k_stream (bb_stream.h): tiles with more pair slots than the register file holds -- the state streamed from memory, the draw
+    recomputed in the G pass, contributions summed per thread and by class over the 16-lane rows -- against the two-kernel step and
+    the literal oracle's loop."""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=3)
+    monkeypatch.setenv("BB_TUNE_LEAD", "100")
+    c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=3)
+
+
 @pytest.mark.parametrize("lead", [100, 50])
 def test_owner_computes_launch_thirtytwo_groups(emu_lib, monkeypatch, lead):
     """self-validating rows with 32 groups (a leader's members fit one batch of eight loads per lane; the consume runs on four

@@ -301,6 +301,34 @@ def test_owner_computes_launch_genotype(hip_lib, name):
     c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name,nb,nthr", [("fitness_neutral_heavy", 140, 1024), ("multienv_T8", 150, 512), ("genotype_T8", 500, 1024), ("genotype_T8", 250, 512),
+                                          ("fitness_T4", 333, 1024)])
+def test_streaming_resident_launch(hip_lib, monkeypatch, name, nb, nthr):
+    """k_stream (bb_stream.h): tiles with more pair slots than the register file holds -- the state streamed from memory, the draw
+    recomputed in the G pass -- against the two-kernel step and the literal oracle's loop (small shapes forced into few large tiles)."""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_STREAM", "1")
+    c.case_persistent_equals_two_kernel(hip_lib, name, expect_kernel=3)
+
+
+def test_streaming_resident_launch_full_size_c5(hip_lib):
+    """BASELINE config 5 on ONE GPU (genotype 200 000 x 8, 5 000 genotypes): k_stream against the two-kernel step, 61 steps."""
+    import os
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import port
+    sp = port.spec_from_workload(synth.genotype_fitness_normal(200_000, 8, 5_000, 45))
+    outs = []
+    for mode in (1, 2):
+        with make_engine(sp, hip_lib, seed=7, launch_mode=mode) as e:
+            e.run(61)
+            outs.append(e.get_params())
+            if mode == 2:
+                assert e.stats()["resident_kernel"] == 3
+    assert np.all(np.isfinite(outs[1][0])) and np.abs(outs[0][0] - outs[1][0]).max() < 1e-8 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-8
+
+
 @pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8", "genotype_odd"])
 def test_genotype_regrouped_inside_the_library(hip_lib, name):
     """geno_idx in order of appearance (a genotype's mutants scattered, as utils.data_to_arrays delivers them): regrouped by the

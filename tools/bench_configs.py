@@ -43,6 +43,6 @@ for name, mk in CFG.items():
     print(json.dumps({"config": name, "steps_per_s": round(n / dt, 1), "us_per_step": round(dt / n * 1e6, 2),
                       "n_latents": st["n_latents"], "bytes_per_step": st["bytes_per_step"],
                       "frac_hbm_peak": round(st["bytes_per_step"] * n / dt / 8e12, 4),
-                      "resident_launch_pairs": st["persistent_pairs"], "resident_kernel": {0: "none (two kernels per step)", 1: "k_persist", 2: "k_res"}[st["resident_kernel"]], "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
+                      "resident_launch_pairs": st["persistent_pairs"], "resident_kernel": {0: "none (two kernels per step)", 1: "k_persist", 2: "k_res", 3: "k_stream"}[st["resident_kernel"]], "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
           flush=True)
     e.close()

@@ -48,7 +48,7 @@ d_impl, d_seed = np.abs(m_g - mu) / s_c, np.abs(mu2 - mu) / s_c
 l_impl, l_seed = np.abs(np.log(s_g) - np.log(s_c)), np.abs(np.log(s_c2) - np.log(s_c))
 q = lambda x: [float(np.quantile(x, v)) for v in (0.5, 0.99, 1.0)]
 out = {
-    "workload": wl.name, "resident_kernel": {0: "two kernels", 1: "k_persist", 2: "k_res"}[resident], "iterations": iters, "gpu_seconds": round(t_gpu, 2), "cpu_port_seconds": round(t_cpu, 2),
+    "workload": wl.name, "resident_kernel": {0: "two kernels", 1: "k_persist", 2: "k_res", 3: "k_stream"}[resident], "iterations": iters, "gpu_seconds": round(t_gpu, 2), "cpu_port_seconds": round(t_cpu, 2),
     "cpu_threads": port.usable_cores(),
     "abs_mean_diff_over_cpu_std [median, p99, max]": {"gpu_vs_cpu_same_stream": q(d_impl), "cpu_seed42_vs_cpu_seed43": q(d_seed)},
     "abs_log_std_diff [median, p99, max]": {"gpu_vs_cpu_same_stream": q(l_impl), "cpu_seed42_vs_cpu_seed43": q(l_seed)},
