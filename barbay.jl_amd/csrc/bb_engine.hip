@@ -569,10 +569,11 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     // the exchange's own loads and stores: at the start of the S pass instead, C2 73.1 -> 77.7 k steps/s, C4 87.1 -> 89.1 k
     // (profiles/r03b_tagged_rows/prefetch_timing_on_lean_kernel.txt) -- where the slot buffer fits beside the moment contributions
     int pf = (ev = getenv("BB_TUNE_PF")) ? atoi(ev) : 1;
-    if (pf < 0 || pf > 2 || h->o.optimizer != BB_OPT_TRUNCATED_ADAGRAD) pf = 0;
+    if (pf < 0 || pf > 3 || h->o.optimizer != BB_OPT_TRUNCATED_ADAGRAD) pf = 0;
     if (stream) pf = 0;
-    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, pf != 0, stream);
-    if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false); }
+    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, pf == 1 || pf == 2, stream);
+    if (pf == 3) Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false);
+    else if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false); }      // (no room for a slot buffer of its own: in the exchange's shadow; pf = 3, behind the exchange, measured 6% slower on C3)
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
     const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
@@ -755,9 +756,9 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, xc, &E.ok);
             else br_xchg_lead<false>(cx, h->M, h->S, A, Y, xc, &E.ok);
         } else if (phase == 3) {
-            if (xg) br_xchg_consume<KIND, PP, true, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok);
-            else if (MSrun) br_xchg_consume<KIND, PP, false, true>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, want_el, ring, smp);
-            else br_xchg_consume<KIND, PP, false, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok);
+            if (xg) br_xchg_consume<KIND, PP, true, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, false, 0, 0, wslot.slot);
+            else if (MSrun) br_xchg_consume<KIND, PP, false, true>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, want_el, ring, smp, last ? wslot.slot : -1);
+            else br_xchg_consume<KIND, PP, false, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, false, 0, 0, wslot.slot);
             // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
             if (MSrun) br_update<KIND, PP, 0, AP, true>(cx, h->M, h->S, A, Y, sb, wslot, buf, h->res_NB, smp, NS);
             else if (!AP && uniform_T(h->M) == 8) br_update<KIND, PP, 8, false>(cx, h->M, h->S, A, Y, sb, wslot, buf, h->res_NB);

@@ -68,6 +68,7 @@ struct BRLay {
     int racc_r[BB_MAX_REP], rw[BB_MAX_REP];   // of the replicate's loglambda segment (rw = its lanes, whole waves; + 4: the 12 columns start in different banks)
     int rowmap;          // [K] int pairs: {lanes per barcode | used << 24, LDS offset of the entry's column (value v of time-pair class k of replicate r)}
     int iG, csum;        // [Ttot] G_t / S_t;  [R] sum_t c_t
+    int rtab;            // [R] int4: per replicate {first time point (tcum), offset of its rows in zl, time points, -} -- for the unit threads' walks
     int ftab;            // [Ttot] int4: what the F pass needs of time point j -- {LDS offset of its five moment totals or -1 (a replicate's last
                          // time point), its index inside s_pop, has a time point before it, -}
     int envt;            // [Ttot] ints: environment of every time point (multienv)
@@ -150,6 +151,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf
     Y.csum = o;    o += BB_MAX_REP;
     o = (o + 1) & ~1;
     Y.ftab = o;    o += 2 * M.Ttot;
+    Y.rtab = o;    o += 2 * M.R;
     Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
     Y.gas = o;     o += M.kind == 2 ? Y.SU : 0;
     Y.seg = o;     o += BR_SEG_DOUBLES * (4 + 4 * M.R + 1);      // (br_build_segs: at most R + 1 + 3 R + 2 segments, + the end marker)
@@ -478,6 +480,10 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
             ft[1] = M.off_t[r] + tt;
             ft[2] = tt > 0 ? 1 : 0;
             ft[3] = 0;
+        }
+        for (int r = tid; r < M.R; r += cx.nthr) {
+            int* rt = (int*)(lds + Y.rtab) + 4 * r;
+            rt[0] = M.tcum[r]; rt[1] = Y.zr0[r]; rt[2] = M.T[r]; rt[3] = 0;
         }
     }
 }
@@ -1094,8 +1100,11 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                         const int th = KIND <= 1 ? 0 : (KIND == 2 ? j - ((st.uo[k][2] >> (16 * x)) & 0xffff) : (is_th ? r * NBs * E : st.thoff[k]));
                         double sv, wv;
                         br_unit_sw<KIND>(lds, Y, buf, o, th, &sv, &wv);
-                        const int T = TT ? TT : M.T[r], tc = KIND <= 1 ? 0 : M.tcum[r];
-                        const double* zr = zbuf + (KIND <= 1 ? Y.zr0[0] : Y.zr0[r]) + bl * (T + 1);
+                        // (per-replicate values from a small LDS table: indexed by a per-lane replicate in the model / layout records they were
+                        //  dependent vector loads from device memory in front of every row walk -- C3's G pass)
+                        const int* rt = (const int*)(lds + Y.rtab) + 4 * r;
+                        const int T = TT ? TT : rt[2], tc = KIND <= 1 ? 0 : rt[0];
+                        const double* zr = zbuf + (KIND <= 1 ? Y.zr0[0] : rt[1]) + bl * (T + 1);
                         double As = 0.0, Qs = 0.0;
                         int nn = 0;
                         if (TT) {
@@ -1226,10 +1235,13 @@ BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const 
 }
 template <int KIND, int P, bool XG, bool MS = false>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
-                            unsigned long long xc, int* ok_slot, bool want_el = false, int ring = 0, int smp = 0) {
+                            unsigned long long xc, int* ok_slot, bool want_el = false, int ring = 0, int smp = 0, int slot = -1) {
     const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
     if (!XG && BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
     else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
+    // pf = 3 (BB_TUNE_PF only): the window slot fetched HERE, behind the exchange and in front of the F pass and the first gradients.
+    // Measured on C3 (no LDS room for pf = 1): 52.7k steps/s against 56.3k with pf = 0 -- the fetch is exposed, not hidden
+    if (A.pf == 3 && slot >= 0) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
     br_finish<KIND, MS>(cx, M, S, Y, &A, want_el, ring, smp);
 }
 
@@ -1286,7 +1298,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
                 br_moments<KIND, P, !XG && BR_TG, MS>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(xc + 1), want_el);
                 br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
                 br_xchg_lead<XG>(cx, M, S, A, Y, xc, ok_slot);
-                br_xchg_consume<KIND, P, XG, MS>(cx, M, S, A, Y, &st, xc, ok_slot, want_el, ring, smp);
+                br_xchg_consume<KIND, P, XG, MS>(cx, M, S, A, Y, &st, xc, ok_slot, want_el, ring, smp, last ? wslot.slot : -1);
                 if (*ok_slot == 0) { stop = true; break; }                 // uniform: read after barrier 3
                 br_update<KIND, P, TT, AP, MS>(cx, M, S, A, Y, &st, wslot, buf, NB, smp, NS);
             }
