@@ -6,6 +6,6 @@ The directory name carries a dot, so import it through the repo-root alias modul
     bb.vi.advi(data=df, model=bb.model.fitness_normal, advi=bb.vi.ADVI(1, 10_000))
 """
 from . import _capi  # noqa: F401
-from ._capi import BarBayHipError, Engine, load_library  # noqa: F401
+from ._capi import BarBayHipError, BarBayNonFinite, Engine, load_library  # noqa: F401
 from . import dist, mcmc, model, sharding, stats, synth, utils, vi  # noqa: F401
 from .model import BarBayError  # noqa: F401

@@ -138,6 +138,7 @@ BB_DEV void bb_prior_of(const DevModel& M, int blk, long long j, double* mean, d
 struct BBLds {
     int zl, zs0, zs1, zs2, zs3, seff, weff, res, As, Qs, acc, wk, Lt, invS, cc, GG, wbar, gglob, misc, part, red, Dt, elbt, seg, zgl, lam;
     int total;
+    int acc_cap;    // doubles of staging at `acc` the cross-GPU consume may use (bbp_consume<true>)
     int tmap;       // k_res: [K] ints, the time point (index into Lt / invS) whose normaliser S_t row entry k is, or -1 (0: no table, bb_put_total searches)
 };
 
@@ -179,6 +180,7 @@ BBLds bb_lds_layout(int R, int E, int kind, int Ttot, int nt1, int K, int NB, in
     L.lam = o;  o += with_lam ? NB * Ttot : 0;   // exp(loglambda sample) of the tile (resident launch only)
     L.res = o;  o += with_lam ? NB * Ttot : 0;   // a_tb = (l[t+1] - l[t]) - s_eff, filled in the exchange's shadow (resident launch only)
     L.total = (o + 1) & ~1;
+    L.acc_cap = (BB_NQ + 1) * nthr;
     L.tmap = 0;
     return L;
 }
@@ -408,9 +410,13 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
         // 5e-5 with one per window early on.  (A per-element "re-add when the sum has fallen 2^16 below its largest value"
         // guard fixes the accuracy -- 8e-9 -- but some wave of the grid trips it at almost every step and the whole lock-stepped
         // grid waits for its 100-slot re-add: 15.3 -> 19.8 us per step.)  So the sum is kept as an unevaluated pair (acc, lo):
-        // both updates go through an error-free two-sum, the rounding errors collect in lo (a float: 53 + 24 bits together, the
-        // sum may fall 2^24 below its peak and still be exact to the last bit of a double).  No re-adds, no divergence, no
-        // window traffic beyond the one slot.
+        // both updates go through an error-free two-sum, the rounding errors collect in lo (a float: 53 + 24 bits together).
+        // What is still lost is lo's own rounding, 2^-77 of the sum per step -- an absolute residue again, 2^24 times smaller
+        // than the plain double's: while the sum falls by 1e13 from its first peak over thousands of steps, the worst latent's sum
+        // is 3e-11 (relative) off the correctly rounded window sum at 1 000 steps, 7e-8 at 5 000, 3e-8 at 10 000, and the step
+        // size eta / (tau + sqrt(s)) moves by at most 1e-8 of itself (tools/window_sum_accuracy.py,
+        // profiles/window_sum_accuracy_10k.json).  A double lo would remove that (+4 VGPRs per pair slot of k_res, +16 B per latent
+        // and step in k_stream); resum_every = k bounds it.  No re-adds, no divergence, no window traffic beyond the one slot.
         double s;
         if (w.resum) {
             s = 0.0;

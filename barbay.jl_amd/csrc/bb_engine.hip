@@ -571,9 +571,9 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     int pf = (ev = getenv("BB_TUNE_PF")) ? atoi(ev) : 1;
     if (pf < 0 || pf > 3 || h->o.optimizer != BB_OPT_TRUNCATED_ADAGRAD) pf = 0;
     if (stream) pf = 0;
-    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, pf == 1 || pf == 2, stream);
-    if (pf == 3) Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false);
-    else if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on, false); }      // (no room for a slot buffer of its own: in the exchange's shadow; pf = 3, behind the exchange, measured 6% slower on C3)
+    BRLay Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on ? 8 * h->o.world_size : 0, pf == 1 || pf == 2, stream);
+    if (pf == 3) Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on ? 8 * h->o.world_size : 0, false);
+    else if (pf != 0 && (size_t)Y.total * 8 > 160 * 1024) { pf = 0; Y = br_layout(h->M, NB, h->nthr, P, h->p2p_on ? 8 * h->o.world_size : 0, false); }      // (no room for a slot buffer of its own: in the exchange's shadow; pf = 3, behind the exchange, measured 6% slower on C3)
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
     const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
@@ -1957,9 +1957,17 @@ extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     BB_ENTER(h);
     int rc = run_enqueue(h, n_steps);
     if (rc) return rc;
-    if ((rc = run_finish(h))) return rc;
+    rc = run_finish(h);
 #ifndef BB_EMU
-    if (h->theta_stale && h->comm) rc = theta_sync_comm(h);       // (collective: every rank ran the same bb_run)
+    if (h->theta_stale && h->comm) {
+        // Collective, so EVERY rank takes it whatever its own launch reported: the timeout word and the non-finite flag run_finish
+        // looks at are this rank's alone, and a rank that returned early here would leave the clean ranks inside ncclAllReduce.
+        // The rank's own error is reported afterwards (the gathered theta rows of a failed run mean nothing, but nobody hangs).
+        const std::string why(g_err);
+        const int rc2 = theta_sync_comm(h);
+        if (rc) snprintf(g_err, sizeof g_err, "%s", why.c_str());
+        else rc = rc2;
+    }
 #endif
     return rc;
 }

@@ -687,7 +687,7 @@ BB_DEV void bbp_consume(BBCtx& cx, const DevModel& M, const DevState& S, const R
         // running sum lives in L.red[k] across chunks
         double* stage = lds + L.acc;
         double* sums = lds + L.red;
-        const int cap = (BB_NQ + 1) * cx.nthr, RC = cap / KK < rows ? cap / KK : rows;
+        const int cap = L.acc_cap, RC = cap / KK < rows ? cap / KK : rows;
         for (int r0 = 0; r0 < rows; r0 += RC) {
             const int nr = rows - r0 < RC ? rows - r0 : RC;
             BB_PASS(cx, tid) {

@@ -114,7 +114,7 @@ static inline
 #ifndef BB_EMU
 __host__ __device__
 #endif
-BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf = false, bool stream = false) {
+BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_hbuf = false, bool stream = false) {
     BRLay Y;
     const int X = (M.kind == 1) ? M.E : (M.kind == 4 ? M.E * M.R : M.R);
     const int KK = M.K + 2 * M.nt1;
@@ -169,21 +169,30 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, bool xg, bool own_hbuf
         Y.rw[r] = r < M.R ? (stream ? (NT / 16) * Y.lpb[r] : (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll)) : 0;
         if (r < M.R) racc_total += BR_NCV * (Y.rw[r] + 4);
     }
+    // Staging of the cross-GPU inbox rows (bbp_consume<true>; xg_rows = 8 x world rows of KK entries, summed in chunks of whole rows):
+    // in use between the publish and the F pass, while the drawn-ahead normals (and, pf = 0, the window slot) wait in the transient
+    // region -- whatever that region has to spare behind them is the staging; only the missing part is added.
+    const int xg_want = xg_rows > 0 ? (xg_rows * KK < (BB_NQ + 1) * NT ? xg_rows * KK : (BB_NQ + 1) * NT) : 0;
+    int busy;           // doubles of the transient region alive during the exchange
     if (stream) {
         Y.hbuf = Y.eps = Y.racc;         // (neither exists: normals and window slots go through registers)
+        busy = racc_total;
         o += racc_total;
     } else if (own_hbuf) {
         // the window slot is fetched while the moment contributions are alive (RunArgs.pf = 1, 2): a region of its own
         Y.eps = Y.racc;
-        { const int need = racc_total > 2 * P * NT ? racc_total : 2 * P * NT; o += need; }
+        busy = 2 * P * NT;
+        { int need = racc_total > busy ? racc_total : busy; if (need < busy + xg_want) need = busy + xg_want; o += need; }
         o = (o + 1) & ~1;
         Y.hbuf = o;    o += 4 * P * NT;
     } else {
         Y.hbuf = Y.racc;
         Y.eps = Y.hbuf + 4 * P * NT;
-        { const int need = racc_total > 6 * P * NT ? racc_total : 6 * P * NT; o += need; }
+        busy = 6 * P * NT;
+        { int need = racc_total > busy ? racc_total : busy; if (need < busy + xg_want) need = busy + xg_want; o += need; }
     }
-    L.acc = o;     o += xg ? (BB_NQ + 1) * NT : 0;     // staging of the cross-GPU inbox rows (bbp_consume<true>): in use while the slot / normals wait
+    L.acc = Y.racc + busy;
+    L.acc_cap = xg_want;
     L.red = o;     o += 2 * 128 + 4 * ((KK + 63) & ~63) + 16;          // (bbp_consume<.., WIDE> / bbp_consume_tg: the second half's partial sums)
     (void)lmax;
     L.total = Y.total = (o + 1) & ~1;

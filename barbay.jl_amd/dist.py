@@ -4,6 +4,9 @@
                                `engine.run(n)` then issues one ncclAllReduce of K doubles per MC sample.
 * `setup_p2p(engine)`       -- the resident multi-GPU launch: IPC handles of the ranks' inboxes all-gathered, mapped,
                                probed, switched on only if EVERY rank can (else the RCCL path stays); returns the verdict.
+* `run(engine, n)`          -- `engine.run(n)` on every rank, then ONE agreement on the outcome: an error any rank saw (a timed-out
+                               exchange and the non-finite flag are rank-local) is raised on EVERY rank, so that nobody walks
+                               into the next collective (`gather_posterior`) alone.
 * `run_external(engine, n)` -- the same step with the reduction done by `torch.distributed.all_reduce`
                                on the host buffer (any backend; this is what the gloo tests drive).
 * `gather_posterior(...)`   -- full (mean, sigma) on every rank from the per-rank shards.
@@ -69,6 +72,23 @@ def setup_p2p(engine) -> bool:
             pass
         return False
     return True
+
+
+def run(engine, n_steps: int) -> None:
+    import torch.distributed as dist
+    from ._capi import BarBayHipError
+    err = None
+    try:
+        engine.run(n_steps)
+    except BarBayHipError as e:          # (the library itself has taken its own collectives before it reported: bb_run)
+        err = e
+    said = [None] * dist.get_world_size()
+    dist.all_gather_object(said, None if err is None else f"{type(err).__name__}: {err}")
+    if err is not None:
+        raise err
+    for r, msg in enumerate(said):
+        if msg is not None:
+            raise BarBayHipError(f"rank {r} failed its run ({msg}); this rank's own run was clean")
 
 
 def run_external(engine, n_steps: int) -> None:

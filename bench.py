@@ -207,7 +207,11 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(st["bytes_per_step"] * steps_per_launch),
                     "algorithmic_bytes_per_step": int(st["bytes_per_step"]), "steps_per_launch": steps_per_launch,
-                    "avg_launch_us": round(launch_s * 1e6, 2), "workgroups": int(st["n_blocks"]), "threads": int(st["block_threads"])}
+                    "avg_launch_us": round(launch_s * 1e6, 2), "workgroups": int(st["n_blocks"]), "threads": int(st["block_threads"]),
+                    # `achieved` / `frac` price the ALGORITHMIC bytes of a step (every latent's state read and written
+                    # once) as the bench contract asks; the state of a resident launch lives in registers, so what actually crosses the
+                    # memory side is `traffic` (counter passes) and its share of the peak is `hbm_side_frac`
+                    "frac_basis": "algorithmic bytes per step / launch time (not counter bytes: see traffic, hbm_side_frac)"}
     elif world == 1:
         eng.run_profiled(args.profile_steps)
         sp = eng.stats()
@@ -221,6 +225,8 @@ def main():
                                                    "algorithmic_bytes_per_launch": int(sp["bytes_sample"])}}}
     if roofline is not None and world > 1:
         roofline["scope"] = "rank 0's GPU and its shard of the bytes"
+        if exchange == "p2p":
+            roofline["kernel_instance"] += ", cross-GPU exchange"
     if roofline is not None and world == 1:
         # `traffic` is NOT measured in this run (PMC counters need rocprofv3 around the process): it is REPLAYED from the last
         # committed counter passes of the same kernel, and only while the device sources are still the ones profiled
@@ -252,6 +258,8 @@ def main():
         if why:
             roofline["traffic_source"] = f"none ({why})"
 
+    if roofline is not None and "kernel_instance" in roofline:
+        roofline["kernel_instance"] += ", ...>"        # (leading template arguments: model kind, pair slots per thread, threads)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
@@ -272,6 +280,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "model": "fitness_normal", "barcodes": wl.B, "timepoints": args.timepoints,
                        "n_latents": int(st["n_latents"]), "samples_per_step": 1,
+                       # which path ran on rank 0 (0: two kernels per step, 1: k_persist, 2: k_res, 3: k_stream), its instance and grid
+                       "resident_kernel": int(st.get("resident_kernel", 0)),
+                       "kernel_instance": (roofline or {}).get("kernel_instance", "k_sample + k_update (two kernels per step)"),
+                       "tiles_per_rank": int(st["n_blocks"]), "threads_per_tile": int(st["block_threads"]),
                        "optimizer": "TruncatedADAGrad(0.1, 40, 100)", "sharding": f"barcodes/{world}",
                        "collective": "none" if world == 1 else (
                            f"resident launch per rank; 8 group rows of {int(st['n_moments'])} + 2(T-1) f64 pushed into every rank's inbox over xGMI per step"

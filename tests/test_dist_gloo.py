@@ -53,3 +53,45 @@ def test_two_ranks_match_one(emu_lib, tmp_path, case):
     mp.spawn(_worker, args=(2, _free_port(), case, g.EMU, str(tmp_path)), nprocs=2, join=True)
     got = np.load(tmp_path / "sharded.npz")
     assert np.abs(got["mean"] - m1).max() < 1e-10 and np.abs(got["sigma"] - s1).max() < 1e-10
+
+
+def _worker_one_fails(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import torch.distributed as dist
+    import barbay_jl_amd as bb
+    from barbay_jl_amd import _capi
+    import _cases as c
+    from conftest import make_engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _capi._declare(ctypes.CDLL(emu_path))
+    sp = c.synth("fitness_multi_tile", seed=4)
+    e = make_engine(sp, lib, seed=5, window=4)       # (one unsharded engine per rank: only the agreement is under test)
+    if rank == 1:
+        mu, om = e.get_params()
+        mu[3] = np.nan                                # this rank's run ends in BarBayNonFinite, rank 0's is clean
+        e.set_params(mu, om)
+    try:
+        bb.dist.run(e, 3)
+        said = "clean"
+    except bb.BarBayNonFinite as err:
+        said = f"own: {err}"
+    except bb.BarBayHipError as err:
+        said = f"told: {err}"
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(said)
+    dist.barrier()                                    # both ranks are still in step: the next collective completes
+    dist.destroy_process_group()
+
+
+def test_a_failed_rank_is_reported_on_every_rank(emu_lib, tmp_path):
+    """dist.run: rank 1 diverges, rank 0 does not -- both raise, and both reach the next collective (a rank-local
+    BarBayNonFinite must not leave the clean ranks alone inside gather_posterior's all-gather)."""
+    import __graft_entry__ as g
+    mp.spawn(_worker_one_fails, args=(2, _free_port(), g.EMU, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (tmp_path / "rank0.txt").read_text(), (tmp_path / "rank1.txt").read_text()
+    assert r0.startswith("told: rank 1 failed its run") and "NonFinite" in r0, r0
+    assert r1.startswith("own:"), r1
