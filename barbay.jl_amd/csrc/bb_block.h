@@ -238,7 +238,9 @@ enum BBSegKind {
     SK_TH_R, SK_TT_R, SK_LT_R, SK_LS_R,   // replicate: theta -> zs3, per-replicate tt / lt / ls -> zs0/1/2 + r NB
     SK_GS, SK_GLS  // global s_pop / logsigma_pop          -> zg (global memory)
 };
-struct BBSeg { long long lo, hi; int pbeg, blk, kind, ldsoff, r, pad; };   // 40 bytes = 5 doubles
+struct BBSeg { long long lo, hi; int pbeg, blk, kind, ldsoff, r, pad; };   // 40 bytes = 5 doubles; pad = bb_hdelta of the segment
+// a segment's latents in a row of the TruncatedADAGrad window: entry = flat index - delta (DevModel.Dh)
+BB_DEV long long bb_hdelta(const DevModel& M, int blk, int r) { return blk == BK_L ? M.hdl[r] : M.hd0[blk] + (long long)r * M.hd1[blk]; }
 
 BB_DEV int bb_seg_pairs(long long lo, long long hi) { return hi > lo ? (int)(((hi - 1) >> 1) - (lo >> 1) + 1) : 0; }
 
@@ -248,7 +250,7 @@ BB_DEV int bb_build_segs(BBSeg* sg, const DevModel& M, const BBLds& L, const BBT
     int n = 0, p = 0;
     auto add = [&](int blk, int kind, long long lo, long long cnt, int ldsoff, int r) {
         if (cnt <= 0) return;
-        BBSeg s; s.lo = lo; s.hi = lo + cnt; s.pbeg = p; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.pad = 0;
+        BBSeg s; s.lo = lo; s.hi = lo + cnt; s.pbeg = p; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.pad = (int)bb_hdelta(M, blk, r);
         sg[n++] = s;
         p += bb_seg_pairs(lo, lo + cnt);
     };
@@ -399,7 +401,7 @@ BB_DEV void bb_two_sum(double a, double b, double* s, double* e) {
     *e = (a - (t - bb)) + (b - bb);
 }
 BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot w,
-                         int which, long long i, double d, double old_slot, double* new_slot, double* p, double* acc, float* lo) {
+                         int which, long long ih /* the latent's entry in a window row */, double d, double old_slot, double* new_slot, double* p, double* acc, float* lo) {
     double upd;
     if (A.opt == 0) {   // TruncatedADAGrad: g2[mod(i-1,n)+1] = d^2; s = sum(g2); d *= eta / (tau + sqrt(s))
         const double n2 = d * d;
@@ -420,7 +422,7 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
         double s;
         if (w.resum) {
             s = 0.0;
-            for (int j = 0; j < A.W; ++j) s += (j == w.slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dp + i];
+            for (int j = 0; j < A.W; ++j) s += (j == w.slot) ? n2 : S.hist[((long long)j * 2 + which) * M.Dh + ih];
             *lo = 0.f;
         } else {
             double t, e1;
@@ -447,7 +449,7 @@ BB_DEV void bb_opt_apply(const DevModel& M, const DevState& S, const RunArgs& A,
 
 // Finish one pair given the likelihood part of d logjoint / d z for its two latents: prior term,
 // reparameterisation gradient w.r.t. (mu, omega), S-sample averaging, entropy term, optimiser.
-BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot w, int blk,
+BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot w, int blk, long long hd,
                            long long i0, bool a0, bool a1, double z0, double z1, double gl0, double gl1) {
     const long long i1 = i0 + 1, blo = M.blk_lo[blk];
     const bool both = a0 && a1;
@@ -482,8 +484,8 @@ BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& 
     double* hs_m = nullptr;
     double* hs_o = nullptr;
     if (A.opt == 0) {
-        hs_m = S.hist + ((long long)w.slot * 2 + 0) * M.Dp;
-        hs_o = S.hist + ((long long)w.slot * 2 + 1) * M.Dp;
+        hs_m = S.hist + ((long long)w.slot * 2 + 0) * M.Dh - hd;          // (hd: where the segment's latents sit in a window row, bb_hdelta)
+        hs_o = S.hist + ((long long)w.slot * 2 + 1) * M.Dh - hd;
     }
     if (both) {
         mu = *(const bb_d2*)(S.mu + i0); om = *(const bb_d2*)(S.om + i0);
@@ -500,12 +502,12 @@ BB_DEV void bb_update_pair(const DevModel& M, const DevState& S, const RunArgs& 
     bb_d2 nhm = hm, nho = ho;
     bb_f4 lo = bb_load_lo(S, i0, a0, a1);
     if (a0) {
-        bb_opt_apply(M, S, A, w, 0, i0, -gm[0], hm.x, &nhm.x, &mu.x, &am.x, &lo.x);
-        bb_opt_apply(M, S, A, w, 1, i0, -go[0], ho.x, &nho.x, &om.x, &ao.x, &lo.y);
+        bb_opt_apply(M, S, A, w, 0, i0 - hd, -gm[0], hm.x, &nhm.x, &mu.x, &am.x, &lo.x);
+        bb_opt_apply(M, S, A, w, 1, i0 - hd, -go[0], ho.x, &nho.x, &om.x, &ao.x, &lo.y);
     }
     if (a1) {
-        bb_opt_apply(M, S, A, w, 0, i1, -gm[1], hm.y, &nhm.y, &mu.y, &am.y, &lo.z);
-        bb_opt_apply(M, S, A, w, 1, i1, -go[1], ho.y, &nho.y, &om.y, &ao.y, &lo.w);
+        bb_opt_apply(M, S, A, w, 0, i1 - hd, -gm[1], hm.y, &nhm.y, &mu.y, &am.y, &lo.z);
+        bb_opt_apply(M, S, A, w, 1, i1 - hd, -go[1], ho.y, &nho.y, &om.y, &ao.y, &lo.w);
     }
     bb_store_lo(S, i0, a0, a1, lo);
     if (both) {
@@ -1052,7 +1054,7 @@ BB_DEV void bb_block_update(BBCtx& cx, const DevModel& M, const DevState& S, con
             else z1 = S.zsv[i0 + 1];
             const double g0 = a0 ? glik(s, i0 - s.lo, z0) : 0.0;
             const double g1 = a1 ? glik(s, i0 + 1 - s.lo, z1) : 0.0;
-            bb_update_pair(M, S, A, wslot, s.blk, i0, a0, a1, z0, z1, g0, g1);
+            bb_update_pair(M, S, A, wslot, s.blk, s.pad, i0, a0, a1, z0, z1, g0, g1);
         });
     }
     BB_SYNC(cx);
@@ -1099,7 +1101,7 @@ BB_DEV void bb_block_geno(BBCtx& cx, const DevModel& M, const DevState& S, const
                 const long long i0 = 2 * ((lo >> 1) + p);
                 const bool a0 = i0 >= lo, a1 = i0 + 1 < hi;
                 const double z0 = a0 ? S.zsv[i0] : 0.0, z1 = a1 ? S.zsv[i0 + 1] : 0.0;
-                bb_update_pair(M, S, A, wslot, BK_S, i0, a0, a1, z0, z1, a0 ? S.gsum[i0 - lo] : 0.0, a1 ? S.gsum[i0 + 1 - lo] : 0.0);
+                bb_update_pair(M, S, A, wslot, BK_S, bb_hdelta(M, BK_S, 0), i0, a0, a1, z0, z1, a0 ? S.gsum[i0 - lo] : 0.0, a1 ? S.gsum[i0 + 1 - lo] : 0.0);
             }
         }
         BB_SYNC(cx);
@@ -1139,8 +1141,8 @@ BB_DEV void bb_block_theta_pack(BBCtx& cx, const DevModel& M, const DevState& S,
                 else buf[i] = own ? (double)*q : 0.0;
                 continue;
             }
-            double* p = a == 0 ? S.mu : (a == 1 ? S.om : (a == 2 ? S.acc_mu : (a == 3 ? S.acc_om : S.hist + (long long)(a - 6) * M.Dp)));
-            p += M.blk_lo[BK_S] + g;
+            double* p = a == 0 ? S.mu : (a == 1 ? S.om : (a == 2 ? S.acc_mu : (a == 3 ? S.acc_om : S.hist + (long long)(a - 6) * M.Dh)));
+            p += M.blk_lo[BK_S] + g - (a < 6 ? 0 : bb_hdelta(M, BK_S, 0));
             if (unpack) *p = buf[i];
             else buf[i] = own ? *p : 0.0;
         }

@@ -219,6 +219,7 @@ struct bb_handle {
     bb_advi_opts o{};
     std::vector<bb_block_range> blocks;
     std::vector<void*> owned;          // device allocations
+    long long dev_bytes = 0;           // ... and their total size
     int NB = 0, nthr = 0, nblk = 0, ngeno_blk = 0;
     size_t lds_doubles = 0;            // dynamic LDS of the two-kernel path
     size_t lds_doubles_p0 = 0;         // ... of the resident launch (adds the lambda table)
@@ -293,6 +294,7 @@ static int dalloc(bb_handle* h, T** p, size_t count) {
     int rc = dmalloc(&q, count * sizeof(T));
     if (rc) return rc;
     h->owned.push_back(q);
+    h->dev_bytes += (long long)(count * sizeof(T));
     *p = (T*)q;
     return dzero(q, count * sizeof(T), h->stream);
 }
@@ -371,6 +373,57 @@ static int upload_prior(bb_handle* h, int kind, const bb_prior* p, double dmean,
 
 struct bb_handle;
 static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
+// Rows of the TruncatedADAGrad window on a SHARDED handle (DevModel.Dh): the window is 2 x window doubles per latent -- a hundred
+// times everything else a handle holds -- and a shard only ever updates its own barcodes' latents, the replicated blocks and (genotype
+// model) the genotype block: one contiguous range of the flat vector per (block, replicate), the ranges every tile's segment table
+// is cut from (bb_build_segs / br_build_segs).  A row packs those ranges one after the other; a segment carries the difference
+// between a latent's flat index and its entry (bb_hdelta), so the kernels pay one subtraction per pair.  Differences are even: pairs
+// stay whole and 16-byte aligned.  BB_NO_HIST_PACK=1 keeps full rows.
+static void hist_rows(bb_handle* h) {
+    DevModel& M = h->M;
+    M.Dh = M.Dp;
+    for (int k = 0; k < BK_COUNT; ++k) M.hd0[k] = M.hd1[k] = 0;
+    for (int r = 0; r < BB_MAX_REP; ++r) M.hdl[r] = 0;
+    const char* ev = getenv("BB_NO_HIST_PACK");
+    if (h->o.world_size <= 1 || (ev && atoi(ev) > 0) || M.Dp >= (1ll << 31)) return;      // (a segment keeps its difference in an int)
+    const long long b0 = h->b_lo, nbt = h->b_hi - h->b_lo;
+    const long long m0 = std::max(h->b_lo, M.nn) - M.nn, nmt = (std::max(h->b_hi, M.nn) - M.nn) - m0;
+    long long c = 0;          // next free entry of the row
+    // one range [a, a + len): starts on an entry of a's parity; two entries of slack (an edge pair's other half is read, never used)
+    auto place = [&](long long a, long long len) { const long long at = c + ((a - c) & 1); c = at + len + 2; return a - at; };
+    // R ranges of one block, `stride` apart in the flat vector, `len` long: packed `lp` apart with lp of the stride's parity
+    auto place_r = [&](int blk, long long a0, long long stride, long long len, int R) {
+        const long long lp = len + 2 + ((stride - (len + 2)) & 1);
+        const long long at = c + ((a0 - c) & 1);
+        M.hd0[blk] = a0 - at;
+        M.hd1[blk] = stride - lp;
+        c = at + (long long)R * lp;
+    };
+    M.hd0[BK_SPOP] = place(M.blk_lo[BK_SPOP], M.blk_hi[BK_SPOP] - M.blk_lo[BK_SPOP]);
+    M.hd0[BK_LSPOP] = place(M.blk_lo[BK_LSPOP], M.blk_hi[BK_LSPOP] - M.blk_lo[BK_LSPOP]);
+    if (M.kind == BB_MODEL_FITNESS || M.kind == BB_MODEL_MULTIENV) {
+        M.hd0[BK_S] = place(M.blk_lo[BK_S] + m0 * M.E, nmt * M.E);
+        M.hd0[BK_LS] = place(M.blk_lo[BK_LS] + m0 * M.E, nmt * M.E);
+    } else if (M.kind == BB_MODEL_GENOTYPE) {
+        M.hd0[BK_S] = place(M.blk_lo[BK_S], M.G);      // (every rank updates every theta_g on the all-reduce step; the resident launch only its own)
+        M.hd0[BK_TT] = place(M.blk_lo[BK_TT] + m0, nmt);
+        M.hd0[BK_LT] = place(M.blk_lo[BK_LT] + m0, nmt);
+        M.hd0[BK_LS] = place(M.blk_lo[BK_LS] + m0, nmt);
+    } else {
+        const long long E_ = M.kind == BB_MODEL_MULTIENV_REPLICATE ? M.E : 1;
+        M.hd0[BK_S] = place(M.blk_lo[BK_S] + m0 * E_, nmt * E_);
+        for (int blk : {BK_TT, BK_LT, BK_LS}) place_r(blk, M.blk_lo[blk] + m0 * E_, M.nb * E_, nmt * E_, M.R);
+    }
+    for (int r = 0; r < M.R; ++r) M.hdl[r] = place(M.off_l[r] + b0 * M.T[r], nbt * M.T[r]);
+    const long long Dh = (c + 7) & ~7ll;
+    if (Dh >= M.Dp) {          // nothing gained (a shard that owns almost everything): full rows, no differences
+        for (int k = 0; k < BK_COUNT; ++k) M.hd0[k] = M.hd1[k] = 0;
+        for (int r = 0; r < BB_MAX_REP; ++r) M.hdl[r] = 0;
+        return;
+    }
+    M.Dh = Dh;
+}
+
 static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
 static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
 static int theta_sync_local(bb_handle* const* hs, int n);
@@ -553,6 +606,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
         nblk = (int)tb.size() - 1;
         if (h->p2p_on && nblk < 8) return false;
     }
+    if (!h->p2p_on && h->M.Dh != h->M.Dp) return false;      // (packed window rows: only the cross-GPU instances read the segments' differences)
     const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
     // more pair slots than the register file holds: k_stream (bb_stream.h) -- the same tile map, the per-pair state streamed
     bool stream = false;
@@ -1208,9 +1262,6 @@ static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
     const size_t D = (size_t)M.D;
     BB_TRY(dalloc(h, &S.mu, D + 2));
     BB_TRY(dalloc(h, &S.om, D + 2));
-    BB_TRY(dalloc(h, &S.zsv, D + 2));
-    BB_TRY(dalloc(h, &S.asv, D + 2));
-    BB_TRY(dalloc(h, &S.hsv, D + 2));
     BB_TRY(dalloc(h, &S.acc_mu, D + 2));
     BB_TRY(dalloc(h, &S.acc_om, D + 2));
     BB_TRY(dalloc(h, &S.accl, 2 * D + 8));
@@ -1221,11 +1272,10 @@ static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
         BB_TRY(h2d(oc, v, sizeof v, h->stream));
         S.optc = oc;
     }
-    BB_TRY(dalloc(h, &S.gacc_mu, D + 2));
-    BB_TRY(dalloc(h, &S.gacc_om, D + 2));
-    BB_TRY(dalloc(h, &h->bak_mu, D + 2));
-    BB_TRY(dalloc(h, &h->bak_om, D + 2));
-    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dp + 8));   // (+ 8: an edge pair's prefetch reads both halves)
+    // (zsv, asv, hsv, gacc_*, bak_*: per-sample scratch of the two-kernel step and of bb_elbo_grad -- ensure_scratch, on first use: a
+    //  shard that only ever runs the resident launch never pays their 7 x 8 D bytes)
+    hist_rows(h);
+    if (opts->optimizer == BB_OPT_TRUNCATED_ADAGRAD) BB_TRY(dalloc(h, &S.hist, (size_t)opts->window * 2 * (size_t)M.Dh + 8));   // (+ 8: an edge pair's prefetch reads both halves)
     BB_TRY(dalloc(h, &S.partials, (size_t)M.K * (size_t)h->nblk));
     BB_TRY(dalloc(h, &S.totals, (size_t)M.K));
     BB_TRY(dalloc(h, &S.zg, (size_t)2 * M.nt1));
@@ -1441,7 +1491,21 @@ static int launch_check() {
 #define LAUNCH_CHECK() launch_check()
 #endif
 
+// Per-sample scratch of the two-kernel step (z, eps sigmoid, sigmoid / softplus), the S > 1 / gradient-export accumulators and
+// bb_elbo_grad's saved parameters: 7 arrays of D doubles, allocated on first use -- every entry point that can reach the
+// two-kernel launchers calls this first (never from inside a stream capture); the resident launches use none of them.
+static int ensure_scratch(bb_handle* h) {
+    if (h->S.zsv) return BB_OK;
+    const size_t D = (size_t)h->M.D;
+    int rc;
+    if ((rc = dalloc(h, &h->S.zsv, D + 2)) || (rc = dalloc(h, &h->S.asv, D + 2)) || (rc = dalloc(h, &h->S.hsv, D + 2)) ||
+        (rc = dalloc(h, &h->S.gacc_mu, D + 2)) || (rc = dalloc(h, &h->S.gacc_om, D + 2)) ||
+        (rc = dalloc(h, &h->bak_mu, D + 2)) || (rc = dalloc(h, &h->bak_om, D + 2))) { h->S.zsv = nullptr; return rc; }
+    return h->dS ? h2d(h->dS, &h->S, sizeof(DevState), h->stream) : BB_OK;      // (kernels read the descriptor through its device copy)
+}
+
 static int launch_sample(bb_handle* h, const RunArgs& A) {
+    if (!h->S.zsv) return bb_fail(BB_ERR_DEVICE, "internal: the two-kernel step's scratch arrays were not allocated (ensure_scratch)");
 #ifdef BB_EMU
     emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) {
         switch (h->M.kind) {
@@ -1458,6 +1522,7 @@ static int launch_sample(bb_handle* h, const RunArgs& A) {
     return LAUNCH_CHECK();
 }
 static int launch_update(bb_handle* h, const RunArgs& A) {
+    if (!h->S.zsv) return bb_fail(BB_ERR_DEVICE, "internal: the two-kernel step's scratch arrays were not allocated (ensure_scratch)");
 #ifdef BB_EMU
     emu_launch(h->nblk, h->nthr, h->lds_doubles, [&](BBCtx& cx) {
         switch (h->M.kind) {
@@ -1482,6 +1547,7 @@ static int launch_reduce(bb_handle* h) {
     return LAUNCH_CHECK();
 }
 static int launch_geno(bb_handle* h, const RunArgs& A, int do_update, int do_sample, int upd_par) {
+    if (!h->S.zsv) return bb_fail(BB_ERR_DEVICE, "internal: the two-kernel step's scratch arrays were not allocated (ensure_scratch)");
 #ifdef BB_EMU
     emu_launch(h->ngeno_blk, 256, 256 + 64, [&](BBCtx& cx) { bb_block_geno(cx, h->M, h->S, A, h->ngeno_blk, do_update, do_sample, upd_par); });
 #else
@@ -1607,7 +1673,7 @@ static int reset_optimizer(bb_handle* h) {
     int rc;
     if ((rc = dzero(h->S.accl, (2 * D + 8) * 4, h->stream))) return rc;
     if (h->o.optimizer == BB_OPT_TRUNCATED_ADAGRAD) {
-        if ((rc = dzero(h->S.hist, (size_t)h->o.window * 2 * (size_t)h->M.Dp * 8, h->stream))) return rc;
+        if ((rc = dzero(h->S.hist, (size_t)h->o.window * 2 * (size_t)h->M.Dh * 8, h->stream))) return rc;
         if ((rc = dzero(h->S.acc_mu, D * 8, h->stream))) return rc;
         if ((rc = dzero(h->S.acc_om, D * 8, h->stream))) return rc;
     } else {
@@ -1754,6 +1820,7 @@ static int group_run(bb_handle* g, int64_t n_steps) {
         const size_t K = (size_t)g->shards[0]->M.K, G = (size_t)g->shards[0]->M.G;
         const bool geno = g->shards[0]->M.kind == BB_MODEL_GENOTYPE;
         std::vector<double> part(std::max(K, G)), total(std::max(K, G));
+        for (bb_handle* sh : g->shards) { BB_ENTER(sh); if ((rc = ensure_scratch(sh))) return rc; }
         auto exchange = [&](size_t n, double* DevState::*buf) -> int {
             std::fill(total.begin(), total.begin() + n, 0.0);
             for (bb_handle* sh : g->shards) {
@@ -1898,6 +1965,7 @@ static int run_enqueue(bb_handle* h, int64_t n_steps) {
     if (h->sample != 0) return bb_fail(BB_ERR_INVALID, "a split-phase step is in flight");
     int rc = 0;
     int64_t done = 0;
+    if (!(h->persist_P > 0) && (rc = ensure_scratch(h))) return rc;
     if (h->hstatus) h->hstatus[1] = 0;          // divergence flag of THIS run (nothing of this handle is in flight here)
 #ifndef BB_EMU
     BB_HIP(hipEventRecord(h->ev0, h->stream));
@@ -1980,6 +2048,7 @@ extern "C" int bb_run_profiled(bb_handle* h, int64_t n_steps) {
     return bb_run(h, n_steps);
 #else
     if (h->use_reduce()) return bb_fail(BB_ERR_UNSUPPORTED, "bb_run_profiled covers the single-GPU two-kernel step only");
+    { const int rcs = ensure_scratch(h); if (rcs) return rcs; }
     const int S = h->o.samples_per_step;
     const size_t nl = (size_t)n_steps * S;
     std::vector<hipEvent_t> ev(3 * nl);
@@ -2037,6 +2106,7 @@ static int elbo_grad_raw(bb_handle* h, const double* mu, const double* omega, co
     if (h->o.world_size > 1 && !eps) return bb_fail(BB_ERR_UNSUPPORTED, "bb_elbo_grad on a sharded handle needs explicit eps");
     const size_t D = (size_t)h->M.D;
     int rc;
+    if ((rc = ensure_scratch(h))) return rc;
     if ((rc = d2d(h->bak_mu, h->S.mu, D * 8, h->stream))) return rc;
     if ((rc = d2d(h->bak_om, h->S.om, D * 8, h->stream))) return rc;
     if ((rc = h2d(h->S.mu, mu, D * 8, h->stream))) return rc;
@@ -2394,6 +2464,7 @@ static int hier_fitness_raw(bb_handle* h, int32_t n_samples, uint64_t seed, doub
     const long long n = bb_hier_units(h);
     const size_t D = (size_t)h->M.D;
     int rc;
+    if ((rc = ensure_scratch(h))) return rc;
     // posterior sigma = softplus(omega) into the (free between steps) z scratch array
     std::vector<double> om(D);
     if ((rc = dsync(h->stream)) || (rc = d2h(om.data(), h->S.om, D * 8, h->stream))) return rc;
@@ -2440,6 +2511,7 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
             if ((rc = bb_get_stats(h->shards[i], &t))) break;
             s->bytes_per_step += t.bytes_per_step; s->bytes_sample += t.bytes_sample; s->bytes_update += t.bytes_update;
             s->n_blocks += t.n_blocks;
+            s->device_bytes += t.device_bytes;
             s->last_run_ms = std::max(s->last_run_ms, t.last_run_ms);
             s->persistent_pairs = std::min(s->persistent_pairs, t.persistent_pairs);
             s->resident_kernel = std::min(s->resident_kernel, t.resident_kernel);
@@ -2458,6 +2530,8 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->shard_hi = h->b_hi;
     s->geno_lo = h->g_lo;
     s->geno_hi = h->g_hi;
+    s->device_bytes = h->dev_bytes;
+    s->window_row = h->M.Dh;
     s->bytes_sample = h->bytes_sample;
     s->bytes_update = h->bytes_update;
     s->bytes_per_step = h->bytes_update;   // theta read once when the two sweeps are fused (96 D + 4 TBR)
@@ -2516,10 +2590,11 @@ extern "C" int bb_step_moments(bb_handle* h, double* partial) {
     if (h->M.kind == BB_MODEL_GENOTYPE && h->o.world_size > 1)
         return bb_fail(BB_ERR_UNSUPPORTED, "split-phase stepping of the sharded genotype model needs a second exchange; use bb_comm_init + bb_run");
     const int S = h->o.samples_per_step;
+    int rc;
+    if ((rc = ensure_scratch(h))) return rc;
     RunArgs A = make_args(h, h->step, h->sample, S, true, elbo_wanted(h, h->step));
     A.red = h->S.totals;   // the caller-reduced totals come back through bb_step_apply
     A.nred = 1;
-    int rc;
     if (h->M.kind == BB_MODEL_GENOTYPE && (rc = launch_geno(h, A, 0, 1, 0))) return rc;
     if ((rc = launch_sample(h, A))) return rc;
     if ((rc = launch_reduce(h))) return rc;
@@ -2535,6 +2610,7 @@ extern "C" int bb_step_apply(bb_handle* h, const double* total) {
     A.red = h->S.totals;
     A.nred = 1;
     int rc;
+    if ((rc = ensure_scratch(h))) return rc;
     if ((rc = h2d(h->S.totals, total, (size_t)h->M.K * 8, h->stream))) return rc;
     if ((rc = update_half(h, A))) return rc;
     if (++h->sample == S) { h->sample = 0; h->step++; }

@@ -281,13 +281,14 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
     BB_PASS(cx, tid) {
         BBPst<P>& st = BB_PSTATE(stv, tid);
         if (A.opt == 0) {
-            const double* hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dp;
-            const double* hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dp;
+            const double* hs_m = S.hist + ((long long)slot * 2 + 0) * M.Dh;
+            const double* hs_o = S.hist + ((long long)slot * 2 + 1) * M.Dh;
 #pragma unroll
             for (int k = 0; k < P; ++k) {
                 const BBPair q = bb_pair_cached(sg, st, k);
-                st.hm[k] = bb_load_pair(hs_m, q.i0, q.a0, q.a1);
-                st.ho[k] = bb_load_pair(hs_o, q.i0, q.a0, q.a1);
+                const long long ih = q.i0 - q.s.pad;
+                st.hm[k] = bb_load_pair(hs_m, ih, q.a0, q.a1);
+                st.ho[k] = bb_load_pair(hs_o, ih, q.a0, q.a1);
             }
         }
     }
@@ -764,8 +765,8 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
         double* hs_m = nullptr;
         double* hs_o = nullptr;
         if (A.opt == 0) {
-            hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dp;
-            hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
+            hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dh;
+            hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dh;
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -793,15 +794,15 @@ BB_DEV void bbp_update(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             const bb_d2 hm = hs_m ? st.hm[k] : bb_d2{0, 0}, ho = hs_m ? st.ho[k] : bb_d2{0, 0};
             bb_d2 nhm = hm, nho = ho;
             if (q.a0) {
-                bb_opt_apply(M, S, A, wslot, 0, q.i0, -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x, &st.lo[k].x);
-                bb_opt_apply(M, S, A, wslot, 1, q.i0, -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x, &st.lo[k].y);
+                bb_opt_apply(M, S, A, wslot, 0, q.i0 - q.s.pad, -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x, &st.lo[k].x);
+                bb_opt_apply(M, S, A, wslot, 1, q.i0 - q.s.pad, -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x, &st.lo[k].y);
             }
             if (q.a1) {
-                bb_opt_apply(M, S, A, wslot, 0, q.i0 + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y, &st.lo[k].z);
-                bb_opt_apply(M, S, A, wslot, 1, q.i0 + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
+                bb_opt_apply(M, S, A, wslot, 0, q.i0 + 1 - q.s.pad, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y, &st.lo[k].z);
+                bb_opt_apply(M, S, A, wslot, 1, q.i0 + 1 - q.s.pad, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
             }
             if (k == 0) BB_STAMP_W(cx, S, 31);
-            if (hs_m) { bb_store_pair(hs_m, q.i0, q.a0, q.a1, nhm); bb_store_pair(hs_o, q.i0, q.a0, q.a1, nho); }
+            if (hs_m) { const long long ih = q.i0 - q.s.pad; bb_store_pair(hs_m, ih, q.a0, q.a1, nhm); bb_store_pair(hs_o, ih, q.a0, q.a1, nho); }
         }
         BB_STAMP_W(cx, S, 19);
     }

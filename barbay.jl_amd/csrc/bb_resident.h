@@ -310,7 +310,8 @@ BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBT
         if (cnt <= 0) return;
         BRSeg s;
         s.lo = lo; s.hi = lo + cnt; s.blk = blk; s.kind = kind; s.ldsoff = ldsoff; s.r = r; s.lpb = lpb; s.T = T;
-        s.rstride = kind == SK_L ? Y.rw[r] + 4 : 0; s.pad = 0;      // (loglambda: stride between the 12 columns of the transposed moment contributions)
+        s.rstride = kind == SK_L ? Y.rw[r] + 4 : 0; s.pad = (int)bb_hdelta(M, blk, r);      // (pad: the segment's place in a window row)
+             // (loglambda: stride between the 12 columns of the transposed moment contributions)
         s.pm = M.pri[blk].mean; s.iv = M.pri[blk].inv_var; s.mean_e = M.pri[blk].mean_e; s.iv_e = M.pri[blk].inv_var_e; s.blo = M.blk_lo[blk];
         if (kind == SK_L) { cur = (cur + 63) & ~63; s.span = (int)(cnt / T) * lpb; }   // (T == 0 only for non-loglambda segments)
         else s.span = bb_seg_pairs(lo, lo + cnt);
@@ -588,7 +589,15 @@ BB_DEV void br_unit_sw(const double* lds, const BRLay& Y, int buf, int o, int th
 // ---- S: draw, stage ---------------------------------------------------------------------------------------------------
 // The long fp64 chains (softplus / sigmoid, exp) run for ALL pair slots without a branch, so that the compiler may interleave
 // the slots' chains; only the stores depend on what the pair is.
-template <int P>
+// A pair's entry in a row of the TruncatedADAGrad window = flat index - its segment's difference (DevModel.Dh, bb_hdelta).  Only a
+// SHARDED handle has differences, and only the cross-GPU instances (HD = XG) run on one: the single-GPU instances skip the LDS read
+// and the 64-bit subtraction at compile time (with them, or behind a run-time flag: C2 80.7 -> 78.5 / 79.2 k steps/s).
+#ifdef BB_EMU
+#define BR_HDELTA(HD, lds, Y, meta) (((const BRSeg*)((lds) + (Y).seg))[(meta) >> 12].pad)
+#else
+#define BR_HDELTA(HD, lds, Y, meta) ((HD) ? ((const BRSeg*)((lds) + (Y).seg))[(meta) >> 12].pad : 0)
+#endif
+template <int P, bool HD = false>
 BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int slot);
 template <int KIND, int P> BB_DEV void br_pair_prior(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, bool a0, bool a1, double* pm0, double* iv0, double* pm1, double* iv1);
 // MS (instances that take several MC samples per step and record the ELBO): want_el -- this sample's ELBO terms are gathered
@@ -596,13 +605,13 @@ template <int KIND, int P> BB_DEV void br_pair_prior(const double* lds, const BR
 //   per (b, t)      R z - lambda                                  (Poisson; bb_pass_moments)
 //   per unit        - logsigma_eff x (time steps that use it)      (normaliser of the fitness likelihood; bb_effective_tables)
 // into BRSt.el; br_moments sums them over the tile (row entry K - 2), br_finish adds the per-time terms and stores the estimate.
-template <int KIND, int P, bool MS = false>
+template <int KIND, int P, bool MS = false, bool HD = false>
 BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int buf, int slot, bool prefetch = true, bool want_el = false) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     BB_STAMP(cx, S, 20);
     BB_STAMP_WAVE(cx, S, A, 1);
-    if (A.pf == 1 && prefetch) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
+    if (A.pf == 1 && prefetch) br_prefetch_slot<P, HD>(cx, M, S, A, Y, stv, slot);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
@@ -853,7 +862,7 @@ BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BR
 // ---- window-slot prefetch (in the exchange's shadow): LDS-DMA, 16 bytes per lane straight into LDS, no register held across the
 // exchange.  Every pair slot fetches both halves of its 16-byte pair (the row is padded: an edge pair's outside half is a
 // neighbour's or the padding, never used). --------------------------------------------------------------------------------------
-template <int P>
+template <int P, bool HD>
 BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, int slot) {
     if (A.opt != 0) return;
     BB_PASS(cx, tid) {
@@ -863,7 +872,7 @@ BB_DEV void br_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, co
             if (!(st.meta[k] & BRM_VALID)) continue;
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
-                const double* src = S.hist + ((long long)slot * 2 + which) * M.Dp + st.i0[k];
+                const double* src = S.hist + ((long long)slot * 2 + which) * M.Dh + (st.i0[k] - BR_HDELTA(HD, cx.lds, Y, st.meta[k]));
                 bb_d2* dst = (bb_d2*)(cx.lds + Y.hbuf) + (k * 2 + which) * cx.nthr;
 #ifdef BB_EMU
                 dst[tid] = bb_d2{src[0], src[1]};
@@ -1039,7 +1048,7 @@ BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int 
 // for the loglambda waves and the whole tile waited for them).
 // MS instances, NS > 1 MC samples per step (AdvancedVI's ELBO estimator, Turing.ADVI(samples_per_step, ..), src/vi.jl:98): sample smp's
 // gradient joins running sums; the last sample averages them, adds the entropy term and updates -- the arithmetic of bb_update_pair.
-template <int KIND, int P, int TT = 0, bool AP = false, bool MS = false>
+template <int KIND, int P, int TT = 0, bool AP = false, bool MS = false, bool HD = false>
 BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                       const BBSlot wslot, int buf, int NBs, int smp = 0, int NS = 1) {
     double* lds = cx.lds;
@@ -1058,8 +1067,8 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
         double* hs_m = nullptr;
         double* hs_o = nullptr;
         if (A.opt == 0) {
-            hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dp;
-            hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
+            hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dh;
+            hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dh;
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -1172,24 +1181,25 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 ho = ((const bb_d2*)(lds + Y.hbuf))[(k * 2 + 1) * cx.nthr + tid];
             }
             bb_d2 nhm = hm, nho = ho;
+            const long long ih = st.i0[k] - BR_HDELTA(HD, lds, Y, meta);          // the pair's entry in a row of the window
             if (a0) {
-                bb_opt_apply(M, S, A, wslot, 0, st.i0[k], -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x, &st.lo[k].x);
+                bb_opt_apply(M, S, A, wslot, 0, ih, -g0, hm.x, &nhm.x, &st.mu[k].x, &st.am[k].x, &st.lo[k].x);
                 BR_SCHED_FENCE();
-                bb_opt_apply(M, S, A, wslot, 1, st.i0[k], -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x, &st.lo[k].y);
+                bb_opt_apply(M, S, A, wslot, 1, ih, -go0, ho.x, &nho.x, &st.om[k].x, &st.ao[k].x, &st.lo[k].y);
                 BR_SCHED_FENCE();
             }
             if (a1) {
-                bb_opt_apply(M, S, A, wslot, 0, st.i0[k] + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y, &st.lo[k].z);
+                bb_opt_apply(M, S, A, wslot, 0, ih + 1, -g1, hm.y, &nhm.y, &st.mu[k].y, &st.am[k].y, &st.lo[k].z);
                 BR_SCHED_FENCE();
-                bb_opt_apply(M, S, A, wslot, 1, st.i0[k] + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
+                bb_opt_apply(M, S, A, wslot, 1, ih + 1, -go1, ho.y, &nho.y, &st.om[k].y, &st.ao[k].y, &st.lo[k].w);
                 BR_SCHED_FENCE();
             }
-            if (hs_m) { br_store_pair_stream<AP>(hs_m, st.i0[k], a0, a1, nhm); br_store_pair_stream<AP>(hs_o, st.i0[k], a0, a1, nho); }
+            if (hs_m) { br_store_pair_stream<AP>(hs_m, ih, a0, a1, nhm); br_store_pair_stream<AP>(hs_o, ih, a0, a1, nho); }
         }
     }
     }
     // (the same thread has just read its entries of the slot buffer: its LDS-DMA of the next step's slot may overwrite them)
-    if (A.pf == 2) br_prefetch_slot<P>(cx, M, S, A, Y, stv, wslot.slot + 1 == A.W ? 0 : wslot.slot + 1);
+    if (A.pf == 2) br_prefetch_slot<P, HD>(cx, M, S, A, Y, stv, wslot.slot + 1 == A.W ? 0 : wslot.slot + 1);
     BB_STAMP_WAVE(cx, S, A, 3);
     BB_STAMP(cx, S, 28);
 }
@@ -1223,12 +1233,12 @@ BB_DEV void br_epilogue(BBCtx& cx, const DevState& S, BRSt<P>* stv, unsigned lon
 // a tile's step between its moments and its update, in three parts (the emulation runs part 2 of all tiles between parts 1 and 3)
 // `xc` numbers the exchanges of a handle's life: the step, or step x S + sample in the instances that take several samples per
 // step; it gives the parity of the double-buffered tables and rows and the rows' epoch.
-template <int KIND, int P, bool AP = false>
+template <int KIND, int P, bool AP = false, bool HD = false>
 BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv, unsigned long long xc, int slot,
                             unsigned long long next_step, unsigned next_stream = 0u, bool prefetch = true) {
     // (the tile's row went out at the end of br_moments)  The window slot first: LDS-DMA is slow to land (~3 k cycles for a
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
-    if (A.pf == 0 && prefetch) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
+    if (A.pf == 0 && prefetch) br_prefetch_slot<P, HD>(cx, M, S, A, Y, stv, slot);
     br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(xc & 1));          // what of this step's gradient needs no totals
     br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, next_step, next_stream);         // the next normals, in the shadow of the rows' flight
 }
@@ -1250,7 +1260,7 @@ BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, con
     else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
     // pf = 3 (BB_TUNE_PF only): the window slot fetched HERE, behind the exchange and in front of the F pass and the first gradients.
     // Measured on C3 (no LDS room for pf = 1): 52.7k steps/s against 56.3k with pf = 0 -- the fetch is exposed, not hidden
-    if (A.pf == 3 && slot >= 0) br_prefetch_slot<P>(cx, M, S, A, Y, stv, slot);
+    if (A.pf == 3 && slot >= 0) br_prefetch_slot<P, XG>(cx, M, S, A, Y, stv, slot);
     br_finish<KIND, MS>(cx, M, S, Y, &A, want_el, ring, smp);
 }
 
@@ -1280,7 +1290,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
         br_draw_ahead<KIND, P, AP>(cx, A, Y, &st, step0);
         BB_STAMP_RT(cx, S, 4);
         BBSlotCtr sc = bb_slot_init(A, step0);
-        if (A.pf == 2) br_prefetch_slot<P>(cx, M, S, A, Y, &st, sc.slot);
+        if (A.pf == 2) br_prefetch_slot<P, XG>(cx, M, S, A, Y, &st, sc.slot);
         const int NS = MS ? A.S : 1;
         // ELBO recording (MS): position inside the recording period and the ring slot, carried like the window slot
         int ec = (MS && A.elbo_every > 0) ? bb_uniform((int)(step0 % (unsigned long long)A.elbo_every)) : 1;
@@ -1303,13 +1313,13 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
 #pragma unroll
                     for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
                 }
-                br_sample<KIND, P, MS>(cx, M, S, A, Y, &st, buf, wslot.slot, last, want_el);
+                br_sample<KIND, P, MS, XG>(cx, M, S, A, Y, &st, buf, wslot.slot, last, want_el);
                 br_moments<KIND, P, !XG && BR_TG, MS>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(xc + 1), want_el);
-                br_xchg_publish<KIND, P, AP>(cx, M, S, A, Y, &st, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
+                br_xchg_publish<KIND, P, AP, XG>(cx, M, S, A, Y, &st, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
                 br_xchg_lead<XG>(cx, M, S, A, Y, xc, ok_slot);
                 br_xchg_consume<KIND, P, XG, MS>(cx, M, S, A, Y, &st, xc, ok_slot, want_el, ring, smp, last ? wslot.slot : -1);
                 if (*ok_slot == 0) { stop = true; break; }                 // uniform: read after barrier 3
-                br_update<KIND, P, TT, AP, MS>(cx, M, S, A, Y, &st, wslot, buf, NB, smp, NS);
+                br_update<KIND, P, TT, AP, MS, XG>(cx, M, S, A, Y, &st, wslot, buf, NB, smp, NS);
             }
             if (stop) break;
             if (MS && A.elbo_every > 0) {

@@ -254,8 +254,8 @@ BB_DEV void bs_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     double* hs_m = nullptr;
     double* hs_o = nullptr;
     if (A.opt == 0) {
-        hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dp;
-        hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dp;
+        hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dh;
+        hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dh;
     }
     // genotype model: pass 0 everything but theta (the theta_tilde thread of every mutant leaves w As in LDS), pass 1 theta
     int th_lo = 0, th_hi = 0;
@@ -278,15 +278,16 @@ BB_DEV void bs_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 bb_d2 am = br_load_pair<false>(S.acc_mu, i0, a0, a1), ao = br_load_pair<false>(S.acc_om, i0, a0, a1);
                 bb_f4 lo = bb_load_lo(S, i0, a0, a1);
                 bb_d2 hm{0, 0}, ho{0, 0};
+                const long long ih = i0 - sg[meta >> 12].pad;
                 if (hs_m) {
 #if !defined(BB_EMU) && BS_NT_HIST
                     if (a0 && a1) {
                         typedef double bs_v2d __attribute__((ext_vector_type(2)));
-                        const bs_v2d x = __builtin_nontemporal_load((const bs_v2d*)(hs_m + i0)), y = __builtin_nontemporal_load((const bs_v2d*)(hs_o + i0));
+                        const bs_v2d x = __builtin_nontemporal_load((const bs_v2d*)(hs_m + ih)), y = __builtin_nontemporal_load((const bs_v2d*)(hs_o + ih));
                         hm = bb_d2{x.x, x.y}; ho = bb_d2{y.x, y.y};
                     } else
 #endif
-                    { hm = br_load_pair<false>(hs_m, i0, a0, a1); ho = br_load_pair<false>(hs_o, i0, a0, a1); }
+                    { hm = br_load_pair<false>(hs_m, ih, a0, a1); ho = br_load_pair<false>(hs_o, ih, a0, a1); }
                 }
                 // the draw of the S pass again (a pure function of seed, latent and step), and what of it the omega gradient needs
                 bb_d2 av, hv;
@@ -333,19 +334,19 @@ BB_DEV void bs_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 const double go0 = fma(g0, av.x, hv.x), go1 = fma(g1, av.y, hv.y);
                 bb_d2 nhm = hm, nho = ho;
                 if (a0) {
-                    bb_opt_apply(M, S, A, wslot, 0, i0, -g0, hm.x, &nhm.x, &mu.x, &am.x, &lo.x);
-                    bb_opt_apply(M, S, A, wslot, 1, i0, -go0, ho.x, &nho.x, &om.x, &ao.x, &lo.y);
+                    bb_opt_apply(M, S, A, wslot, 0, ih, -g0, hm.x, &nhm.x, &mu.x, &am.x, &lo.x);
+                    bb_opt_apply(M, S, A, wslot, 1, ih, -go0, ho.x, &nho.x, &om.x, &ao.x, &lo.y);
                 }
                 if (a1) {
-                    bb_opt_apply(M, S, A, wslot, 0, i0 + 1, -g1, hm.y, &nhm.y, &mu.y, &am.y, &lo.z);
-                    bb_opt_apply(M, S, A, wslot, 1, i0 + 1, -go1, ho.y, &nho.y, &om.y, &ao.y, &lo.w);
+                    bb_opt_apply(M, S, A, wslot, 0, ih + 1, -g1, hm.y, &nhm.y, &mu.y, &am.y, &lo.z);
+                    bb_opt_apply(M, S, A, wslot, 1, ih + 1, -go1, ho.y, &nho.y, &om.y, &ao.y, &lo.w);
                 }
                 br_store_pair<false>(S.mu, i0, a0, a1, mu);
                 br_store_pair<false>(S.om, i0, a0, a1, om);
                 br_store_pair<false>(S.acc_mu, i0, a0, a1, am);
                 br_store_pair<false>(S.acc_om, i0, a0, a1, ao);
                 bb_store_lo(S, i0, a0, a1, lo);
-                if (hs_m) { br_store_pair_stream<false>(hs_m, i0, a0, a1, nhm); br_store_pair_stream<false>(hs_o, i0, a0, a1, nho); }
+                if (hs_m) { br_store_pair_stream<false>(hs_m, ih, a0, a1, nhm); br_store_pair_stream<false>(hs_o, ih, a0, a1, nho); }
                 const double chk = (a0 ? mu.x + om.x : 0.0) + (a1 ? mu.y + om.y : 0.0);
                 bad = bad || !(chk - chk == 0.0);
             }

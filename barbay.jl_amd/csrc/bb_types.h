@@ -28,7 +28,15 @@ struct DevPrior {
 struct DevModel {
     int kind, R, E, G;
     long long nn, nb, B, D;
-    long long Dp;                     // D rounded up to a multiple of 8: stride of the optimiser-history slots (16-B aligned pairs)
+    long long Dp;                     // D rounded up to a multiple of 8
+    // The TruncatedADAGrad window [W][2][Dh].  A whole-problem handle: Dh = Dp, entry i of a row is latent i.  A SHARDED handle
+    // keeps only the latents it ever updates -- its barcodes' latents, the replicated blocks, the genotype block: one contiguous
+    // range per (block, replicate), the ranges a tile's segment table is cut from -- packed one after the other (bb_engine.hip,
+    // hist_rows): latent i of block blk, replicate r sits at entry i - bb_hdelta(M, blk, r).  All deltas are even (pairs stay
+    // whole and 16-byte aligned) and zero on a whole-problem handle.
+    long long Dh;
+    long long hd0[BK_COUNT], hd1[BK_COUNT];   // per-mutant and replicated blocks: delta = hd0[blk] + r hd1[blk]
+    long long hdl[BB_MAX_REP];                // loglambda slab of replicate r
     int T[BB_MAX_REP];
     unsigned Tmagic[BB_MAX_REP];      // floor(2^32 / T) + 1: n / T == umulhi(n, magic) for n < 2^16
     unsigned Tmagic1[BB_MAX_REP];     // same for T - 1

@@ -157,6 +157,9 @@ typedef struct bb_stats {
     int32_t geno_lo, geno_hi;  /* genotype model: the genotypes whose theta THIS handle owns (0 .. n_geno unless the run is
                                   sharded and geno_idx is non-decreasing: shards are then cut at genotype boundaries, and after
                                   a resident run only the owner's copy of theta_g is current)                          */
+    int64_t device_bytes;      /* device memory this handle allocated (a multi-device handle: all its shards)          */
+    int64_t window_row;        /* entries of one row of the TruncatedADAGrad window: n_latents rounded up to 8 on a
+                                  whole-problem handle; a shard keeps only the latents it updates (folded rows)        */
 } bb_stats;
 
 const char* bb_version(void);

@@ -334,7 +334,7 @@ def test_baseline_shards_run_the_owner_computes_launch(emu_lib, cfg, world):
           "C4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
           "C5": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45)}[cfg]()
     es = [bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=42, rank=r, world_size=world,
-                    window=2, _lib=emu_lib) for r in range(world)]   # (window: geometry does not depend on it; 100 slots are 0.8 GB per handle)
+                    _lib=emu_lib) for r in range(world)]   # (the default 100-slot window: a shard keeps only its own latents' rows)
     try:
         handles = [e.p2p_export() for e in es]
         for e in es:
@@ -345,6 +345,14 @@ def test_baseline_shards_run_the_owner_computes_launch(emu_lib, cfg, world):
         assert all(s["resident_kernel"] == 2 and s["n_blocks"] >= 8 for s in st), st
         if cfg != "C5":
             assert all(s["persistent_pairs"] == 1 for s in st), st
+        # the memory is sharded with the work: a row of the TruncatedADAGrad window holds the shard's own latents (+ the replicated
+        # blocks), not all D, and the two-kernel step's scratch arrays are not allocated on a handle that runs the resident launch
+        D = st[0]["n_latents"]
+        assert all(s["window_row"] <= D / world * 1.06 + 6_000 for s in st), [(s["window_row"], D) for s in st]
+        full = 100 * 2 * 8 * D + 12 * 8 * D                 # what every rank used to allocate: the whole window + 12 D-sized arrays
+        assert all(s["device_bytes"] < full / world + 6 * 8 * D + 64e6 for s in st), [s["device_bytes"] for s in st]
+        if cfg == "C5":
+            assert all(s["device_bytes"] <= 0.6e9 for s in st), [s["device_bytes"] for s in st]      # (3.7 GB per rank before)
     finally:
         for e in es:
             e.close()
