@@ -42,7 +42,7 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def main(fetch_dir, write_dir, kernel, steps, tag):
+def main(fetch_dir, write_dir, kernel, steps, tag, out_path=None):
     f, fn = per_dispatch(counter_rows(fetch_dir), "FETCH_SIZE", kernel)
     w, _ = per_dispatch(counter_rows(write_dir), "WRITE_SIZE", kernel)
     if not f or not w:
@@ -56,9 +56,9 @@ def main(fetch_dir, write_dir, kernel, steps, tag):
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled (gfx950 "
                    "under-reports 16 B/lane streaming reads by 2x); counts fabric traffic beyond L2 incl. Infinity-Cache hits",
            "source": tag}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)
+    json.dump(out, open(out_path or os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)      # (another path: a config other than bench.py's)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "")
+    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "", sys.argv[6] if len(sys.argv) > 6 else None)

@@ -11,7 +11,7 @@ from barbay_jl_amd import synth  # noqa: E402
 cfg = os.environ.get("CFG", "C3")
 wl = {"C2": lambda: synth.fitness_normal(50_000, 8, 42), "C3": lambda: synth.replicate_fitness_normal(20_000, 6, 3, 43),
       "C4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
-      "C5rank": lambda: synth.genotype_fitness_normal(25_000, 8, 625, 45)}[cfg]()
+      "C5rank": lambda: synth.genotype_fitness_normal(25_000, 8, 625, 45), "C5": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45)}[cfg]()
 steps = int(os.environ.get("STEPS", 4000))
 e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=1)
 e.run(200)
