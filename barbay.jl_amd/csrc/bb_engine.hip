@@ -803,7 +803,7 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             if (MSrun) br_sample<KIND, PP, true>(cx, h->M, h->S, A, Y, sb, buf, wslot.slot, last, want_el);
             else br_sample<KIND, PP, false>(cx, h->M, h->S, A, Y, sb, buf, wslot.slot);
             const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
-            if (xg || !BR_TG) { if (MSrun) br_moments<KIND, PP, false, true>(cx, h->M, h->S, Y, sb, buf, epoch, want_el); else br_moments<KIND, PP, false, false>(cx, h->M, h->S, Y, sb, buf, epoch); }
+            if (!BR_TG) { if (MSrun) br_moments<KIND, PP, false, true>(cx, h->M, h->S, Y, sb, buf, epoch, want_el); else br_moments<KIND, PP, false, false>(cx, h->M, h->S, Y, sb, buf, epoch); }
             else { if (MSrun) br_moments<KIND, PP, true, true>(cx, h->M, h->S, Y, sb, buf, epoch, want_el); else br_moments<KIND, PP, true, false>(cx, h->M, h->S, Y, sb, buf, epoch); }
             br_xchg_publish<KIND, PP, AP>(cx, h->M, h->S, A, Y, sb, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
         } else if (phase == 2) {

@@ -432,7 +432,14 @@ BB_DEV bool bb_gran_poll8(const bb_gran* base, unsigned off, unsigned stride, in
 #endif
 }
 
-// leader of group g = tile g: its members' rows (16 at most per batch of two polls), summed in member order, out as the group row
+BB_DEV long long bbx_slot(const RunArgs& A, int par, int src, int g);
+BB_DEV void bb_st_sys(double* p, double v);
+BB_DEV void bb_set_word_sys(unsigned* word, unsigned v);
+// leader of group g = tile g: its members' rows (16 at most per batch of two polls), summed in member order, out as the group row.
+// XG: the first hop is the same (the members are this rank's own tiles); the group row then goes into EVERY rank's inbox with
+// system-scope stores, drained, and the inboxes' ready words follow (the cross-GPU hop keeps its ready words: whether a 16-byte
+// store stays whole across xGMI could not be established on a one-GPU box).
+template <bool XG = false>
 BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int par, unsigned epoch, int* ok) {
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A), g = cx.block;
     const int members = (A.nblk - g + NG - 1) / NG;
@@ -448,8 +455,14 @@ BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s += v[i];
             }
-            if (act) bb_gran_st(S.gxrow + ((long long)par * NG + g) * KK + k, s, epoch);
+            if (XG) {
+                if (act) for (int r = 0; r < A.world; ++r) bb_st_sys(S.xout[r] + bbx_slot(A, par, A.rank, g) * KK + k, s);
+            } else if (act) bb_gran_st(S.gxrow + ((long long)par * NG + g) * KK + k, s, epoch);
         }
+    }
+    if (XG) {
+        bb_drain_and_meet(cx);
+        BB_PASS(cx, tid) { if (tid < A.world) bb_set_word_sys(S.xout_rdy[tid] + 32 * bbx_slot(A, par, A.rank, g), epoch); }
     }
     BB_STAMP(cx, S, 18);
 }

@@ -1248,7 +1248,7 @@ BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const 
     // (fetching the members' rows in one round trip -- two waves, 16 members each, partial sums through LDS -- measured SLOWER,
     //  as round 1 had found for k_persist: 7.6 k cycles against 4.8 k for the leader's read + sum + publish)
     if (cx.block < bbp_groups(A)) {
-        if (!XG && BR_TG) bbp_leader_reduce_tg(cx, M, S, A, (int)(xc & 1), epoch, ok_slot);
+        if (BR_TG) bbp_leader_reduce_tg<XG>(cx, M, S, A, (int)(xc & 1), epoch, ok_slot);
         else bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
     }
 }
@@ -1314,7 +1314,7 @@ __global__ void __launch_bounds__(NT) k_res(const DevModel* __restrict__ Mp, con
                     for (int k = 0; k < P; ++k) asm volatile("" : "+v"(st.meta[k]));
                 }
                 br_sample<KIND, P, MS, XG>(cx, M, S, A, Y, &st, buf, wslot.slot, last, want_el);
-                br_moments<KIND, P, !XG && BR_TG, MS>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(xc + 1), want_el);
+                br_moments<KIND, P, BR_TG != 0, MS>(cx, M, S, Y, &st, buf, A.xepoch0 + (unsigned)(xc + 1), want_el);      // (tagged rows on the first hop of the sharded instances too)
                 br_xchg_publish<KIND, P, AP, XG>(cx, M, S, A, Y, &st, xc, wslot.slot, last ? step + 1 : step, last ? 0u : (unsigned)(smp + 1), last);
                 br_xchg_lead<XG>(cx, M, S, A, Y, xc, ok_slot);
                 br_xchg_consume<KIND, P, XG, MS>(cx, M, S, A, Y, &st, xc, ok_slot, want_el, ring, smp, last ? wslot.slot : -1);
