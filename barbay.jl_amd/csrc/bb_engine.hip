@@ -237,7 +237,7 @@ struct bb_handle {
     std::vector<double> ld_omega, ld_zero;   // bb_logdensity_grad: constant omega / eps arguments
     // cross-GPU leg of the resident launch (bb_p2p_*)
     void* p2p_inbox = nullptr;               // this rank's inbox (fine-grained device memory)
-    size_t p2p_rows_bytes = 0, p2p_bytes = 0;
+    size_t p2p_rows_bytes = 0, p2p_bytes = 0, p2p_gran_off = 0;
     void* p2p_peer[BB_MAX_WORLD] = {};       // peers' inboxes as mapped here
     bool p2p_ready = false, p2p_on = false;
     unsigned p2p_seq = 0;                    // probe sequence number (tokens only ever grow)
@@ -560,12 +560,16 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     int NB0 = h->NB, nblk0 = h->nblk;
     if (nblk0 > h->cus && !getenv("BB_TUNE_NB")) { NB0 = (int)((nbar + h->cus - 1) / h->cus); nblk0 = (int)((nbar + NB0 - 1) / NB0); }
     int NB = NB0, NBL = 0, nblk = nblk0;
-    // groups of the exchange's first hop: 16 on one GPU where the grid is large and the tile has two thread groups for the consume
-    // (bbp_consume<.., WIDE>); the cross-GPU inbox protocol is laid out for 8.  BB_TUNE_NG overrides (8 or 16).
-    if (!h->p2p_on && h->M.K + 2 * h->M.nt1 > h->nthr) return false;      // (bbp_consume<.., WIDE>: one thread per row entry)
+    // Groups of the exchange's first hop.  Round 2: 16 on one GPU (a leader then fetched its 16 members' rows in one round of loads, the
+    // consume ran on two thread groups).  Round 3, tagged rows + leaders that poll their members in chunks of eight on as many thread
+    // groups as the tile has (bbp_leader_reduce_tg, PAR): 8 groups of 32 are ONE round of polls where the tile has four thread groups, and
+    // every tile's consume is one thread group's eight loads -- C2 82.7 -> 83.5 k steps/s, C4 94.1 -> 94.9 k, C3 57.1 -> 57.7 k against 16
+    // (profiles/r03g_parallel_leaders).  The cross-GPU inbox protocol is laid out for 8.  BB_TUNE_NG overrides (8 or 16).
+    if (h->M.K + 2 * h->M.nt1 > h->nthr) return false;      // (one thread per row entry: bbp_consume_tg / _tgx, the leaders' chunk sums)
     {
         const int KK = h->M.K + 2 * h->M.nt1;
-        int ng = (!h->p2p_on && nblk0 >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)) ? 16 : 8;
+        const bool can16 = !h->p2p_on && nblk0 >= 64 && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128);
+        int ng = (can16 && !(BR_TG && BR_LEAD_PAR && h->nthr >= 4 * ((KK + 63) & ~63))) ? 16 : 8;
         if ((ev = getenv("BB_TUNE_NG")) && (atoi(ev) == 8 || (atoi(ev) == 16 && !h->p2p_on && KK <= 128 && h->nthr >= 2 * (KK <= 64 ? 64 : 128)))) ng = atoi(ev);
 #if BR_TG
         // self-validating rows: a leader takes its members' rows in batches of eight loads per lane -- 32 groups of 8 on a full grid:
@@ -1787,6 +1791,8 @@ static int group_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
         }
     }
     if (ok) for (int i = 0; i < n && ok; ++i) ok = bb_p2p_enable(g->shards[i], 1) == BB_OK;
+    // the two resident kernels speak different inbox protocols (k_res: tagged entries, k_persist: rows + ready words): all shards the same one
+    if (ok) for (int i = 1; i < n && ok; ++i) ok = (g->shards[i]->res_P > 0) == (g->shards[0]->res_P > 0);
     if (!ok) for (bb_handle* sh : g->shards) if (sh->p2p_ready) (void)bb_p2p_enable(sh, 0);
     g->group_resident = ok;
     if (!ok && opts->launch_mode == 2) {
@@ -2256,13 +2262,15 @@ static void p2p_release(bb_handle* h) {
 
 // this rank's inbox: fine-grained device memory (remote stores and local polls must meet in memory, not in either side's L2)
 static int p2p_alloc_inbox(bb_handle* h) {
-    if (h->o.world_size < 2) return bb_fail(BB_ERR_INVALID, "the cross-GPU leg needs a sharded handle (world_size > 1)");
+    // (BB_P2P_SELF=1, diagnostics: a whole-problem handle runs the inbox protocol against its own inbox -- tools/xg_self.py)
+    if (h->o.world_size < 2 && !(getenv("BB_P2P_SELF") && atoi(getenv("BB_P2P_SELF")) > 0)) return bb_fail(BB_ERR_INVALID, "the cross-GPU leg needs a sharded handle (world_size > 1)");
     if (h->o.world_size > BB_MAX_WORLD) return bb_fail(BB_ERR_UNSUPPORTED, "at most %d ranks", BB_MAX_WORLD);
     if (h->M.kind == BB_MODEL_GENOTYPE && !h->M.geno_sorted)
         return bb_fail(BB_ERR_UNSUPPORTED, "the genotype model's resident launch needs geno_idx in consecutive runs (shards must own whole genotypes)");
     if (h->p2p_inbox) return BB_OK;
     h->p2p_rows_bytes = p2p_rows_bytes(h);
-    h->p2p_bytes = h->p2p_rows_bytes + (p2p_probe_words_off(h) + (size_t)32 * h->o.world_size) * 4;
+    h->p2p_gran_off = (h->p2p_rows_bytes + (p2p_probe_words_off(h) + (size_t)32 * h->o.world_size) * 4 + 255) & ~(size_t)255;
+    h->p2p_bytes = h->p2p_gran_off + 2 * h->p2p_rows_bytes + 16 * 16 * (size_t)(h->M.K + 2 * h->M.nt1);      // (tagged rows: 16 B per entry; + the polls' eight-rows-in-flight slack)
 #ifdef BB_EMU
     h->p2p_inbox = calloc(1, h->p2p_bytes);
     if (!h->p2p_inbox) return bb_fail(BB_ERR_DEVICE, "out of memory");
@@ -2281,6 +2289,7 @@ static int p2p_wire(bb_handle* h, void* const* bases) {
         h->p2p_peer[r] = bases[r];
         h->S.xout[r] = (double*)bases[r];
         h->S.xout_rdy[r] = (unsigned*)((char*)bases[r] + h->p2p_rows_bytes);
+        h->S.xgr[r] = (bb_gran*)((char*)bases[r] + h->p2p_gran_off);
     }
     h->p2p_ready = true;
     return sync_descriptors(h);

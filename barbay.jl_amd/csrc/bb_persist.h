@@ -363,6 +363,10 @@ struct alignas(16) bb_gran { unsigned lo, t0, hi, t1; };
 #ifndef BB_EMU
 typedef unsigned bb_v4u __attribute__((ext_vector_type(4)));
 #endif
+// SYS: system scope (sc0 sc1) -- an entry of a PEER's inbox, written over xGMI.  Each 8-byte half carries the tag, so the entry
+// validates itself as long as the fabric keeps aligned 8-byte writes whole (every PCIe / xGMI transport does); no ordering between
+// entries, or between the halves, is assumed.
+template <bool SYS = false>
 BB_DEV void bb_gran_st(bb_gran* p, double v, unsigned tag) {
 #ifdef BB_EMU
     unsigned long long b;
@@ -370,7 +374,8 @@ BB_DEV void bb_gran_st(bb_gran* p, double v, unsigned tag) {
     *p = bb_gran{(unsigned)b, tag, (unsigned)(b >> 32), tag};
 #else
     bb_v4u g = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
+    if (SYS) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(g) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
 #endif
 }
 // The entries base[off + i * stride], i < 8: poll until those with i < n carry `tag` in both halves, then their values in order
@@ -378,6 +383,7 @@ BB_DEV void bb_gran_st(bb_gran* p, double v, unsigned tag) {
 // per lane: ONE address register for the eight loads in flight (scalar base + 32-bit lane offset, advanced between the loads) --
 // with eight 64-bit lane addresses beside the 32 destination registers the step loop of the 1024-thread instances spilled.  One
 // call per thread with a row entry; the lanes of a wave leave together.  false = gave up.
+template <bool SYS = false>
 BB_DEV bool bb_gran_poll8(const bb_gran* base, unsigned off, unsigned stride, int n, unsigned tag, bool active, unsigned* tmo, unsigned limit, double* out) {
 #ifdef BB_EMU
     (void)tmo; (void)limit;
@@ -400,17 +406,20 @@ BB_DEV bool bb_gran_poll8(const bb_gran* base, unsigned off, unsigned stride, in
     const unsigned long long sbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bp);
     for (unsigned spins = 0;; ++spins) {
         unsigned vo = off * 16u;
-        asm volatile("global_load_dwordx4 %0, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %1, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %2, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %3, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %4, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %5, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %6, %8, %9 sc1\n\t" "v_add_u32 %8, %10, %8\n\t"
-                     "global_load_dwordx4 %7, %8, %9 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7), "+v"(vo)
-                     : "s"(sbase), "s"(sb) : "memory");
+#define BB_POLL8(SC) \
+        asm volatile("global_load_dwordx4 %0, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %1, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %2, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %3, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %4, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %5, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %6, %8, %9 " SC "\n\t" "v_add_u32 %8, %10, %8\n\t" \
+                     "global_load_dwordx4 %7, %8, %9 " SC "\n\t" \
+                     "s_waitcnt vmcnt(0)" \
+                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7), "+v"(vo) \
+                     : "s"(sbase), "s"(sb) : "memory")
+        if (SYS) BB_POLL8("sc0 sc1"); else BB_POLL8("sc1");
+#undef BB_POLL8
         const bool good = ((g0.y == tag && g0.w == tag) || n < 1) && ((g1.y == tag && g1.w == tag) || n < 2) && ((g2.y == tag && g2.w == tag) || n < 3) &&
                           ((g3.y == tag && g3.w == tag) || n < 4) && ((g4.y == tag && g4.w == tag) || n < 5) && ((g5.y == tag && g5.w == tag) || n < 6) &&
                           ((g6.y == tag && g6.w == tag) || n < 7) && ((g7.y == tag && g7.w == tag) || n < 8);
@@ -436,15 +445,56 @@ BB_DEV long long bbx_slot(const RunArgs& A, int par, int src, int g);
 BB_DEV void bb_st_sys(double* p, double v);
 BB_DEV void bb_set_word_sys(unsigned* word, unsigned v);
 // leader of group g = tile g: its members' rows (16 at most per batch of two polls), summed in member order, out as the group row.
-// XG: the first hop is the same (the members are this rank's own tiles); the group row then goes into EVERY rank's inbox with
-// system-scope stores, drained, and the inboxes' ready words follow (the cross-GPU hop keeps its ready words: whether a 16-byte
-// store stays whole across xGMI could not be established on a one-GPU box).
+// XG: the first hop is the same (the members are this rank's own tiles); the group row then goes into EVERY rank's inbox as
+// tagged entries written with system-scope stores (bb_gran_st<true>): no drain, no meet, no ready words on the cross-GPU hop either.
+// PAR (the sharded instances: 8 groups, up to 33 members): the members go in chunks of eight to as many thread groups as the tile
+// has, all polling at once; the chunk sums cross through LDS and are added in chunk order -- one round of polls instead of four.
+#ifndef BR_LEAD_PAR
+#define BR_LEAD_PAR 1          /* 1: the one-GPU instances too (measured: C2 80.8 -> 82.6 k steps/s, C4 90.7 -> 93.9 k at 16 groups; 0 = round-3 form before) */
+#endif
 template <bool XG = false>
-BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, int par, unsigned epoch, int* ok) {
+BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par, unsigned epoch, int* ok) {
     const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A), g = cx.block;
     const int members = (A.nblk - g + NG - 1) / NG;
+    constexpr bool PAR = XG || BR_LEAD_PAR;
+    const int KKP = (KK + 63) & ~63, chunks = (members + 7) >> 3;
+    if (PAR && chunks > 1 && cx.nthr >= 2 * KKP) {
+        double* lds = cx.lds;
+        int NQ = cx.nthr / KKP;
+        if (NQ > chunks) NQ = chunks;
+        BB_PASS(cx, tid) {
+            int q = 0;
+            for (int t = KKP; t <= tid && q < NQ; t += KKP) ++q;
+            const int kk = tid - q * KKP;
+            if (q < NQ) {
+                const bool act = kk < KK;
+                const int k = act ? kk : KK - 1;
+                for (int c = q; c < chunks; c += NQ) {
+                    double v[8];
+                    const int m0 = 8 * c, n = members - m0 < 8 ? members - m0 : 8;
+                    if (!bb_gran_poll8(S.grow + (long long)g * KK, (unsigned)(m0 * NG * KK + k), (unsigned)(NG * KK), n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
+                    double s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s += v[i];
+                    if (act) lds[L.red + c * KKP + kk] = s;
+                }
+            }
+        }
+        BB_SYNC(cx);
+        BB_PASS(cx, tid) {
+            if (tid < KK) {
+                double s = lds[L.red + tid];
+                for (int c = 1; c < chunks; ++c) s += lds[L.red + c * KKP + tid];
+                if (XG) { for (int r = 0; r < A.world; ++r) bb_gran_st<true>(S.xgr[r] + bbx_slot(A, par, A.rank, g) * KK + tid, s, epoch); }
+                else bb_gran_st(S.gxrow + ((long long)par * NG + g) * KK + tid, s, epoch);
+            }
+        }
+        BB_SYNC(cx);          // (the chunk sums' LDS is the consume's as well)
+        BB_STAMP(cx, S, 18);
+        return;
+    }
     BB_PASS(cx, tid) {
-        if (tid < ((KK + 63) & ~63)) {             // (whole waves: the lanes of a wave poll together)
+        if (tid < KKP) {             // (whole waves: the lanes of a wave poll together)
             const bool act = tid < KK;
             const int k = act ? tid : KK - 1;
             double s = 0.0;
@@ -456,13 +506,9 @@ BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S
                 for (int i = 0; i < 8; ++i) s += v[i];
             }
             if (XG) {
-                if (act) for (int r = 0; r < A.world; ++r) bb_st_sys(S.xout[r] + bbx_slot(A, par, A.rank, g) * KK + k, s);
+                if (act) for (int r = 0; r < A.world; ++r) bb_gran_st<true>(S.xgr[r] + bbx_slot(A, par, A.rank, g) * KK + k, s, epoch);
             } else if (act) bb_gran_st(S.gxrow + ((long long)par * NG + g) * KK + k, s, epoch);
         }
-    }
-    if (XG) {
-        bb_drain_and_meet(cx);
-        BB_PASS(cx, tid) { if (tid < A.world) bb_set_word_sys(S.xout_rdy[tid] + 32 * bbx_slot(A, par, A.rank, g), epoch); }
     }
     BB_STAMP(cx, S, 18);
 }
@@ -504,6 +550,47 @@ BB_DEV void bbp_consume_tg(BBCtx& cx, const DevModel& M, const DevState& S, cons
 #endif
             double s = s0;
             for (int q = 1; q < NQ; ++q) s += lds[L.red + (q - 1) * KKP + tid];
+            if (tid < M.K) bb_put_total(M, L, lds, tid, s);
+            else lds[L.zgl + (tid - M.K)] = s;
+        }
+    }
+    if (!(KK <= 64 && M.Ttot <= 64)) BB_SYNC(cx);
+}
+
+// Sharded k_res: the 8 x world group rows of this rank's own inbox (tagged entries, written by every rank's leaders over xGMI, polled
+// here as local memory with system-scope loads).  Rows come in chunks of eight -- chunk c = rows [8 c, 8 c + 8) = source rank c's
+// eight groups -- each summed in row order by one thread group; the chunk sums cross through LDS and are added in chunk order:
+// the order depends on nothing but (rank, group), so every rank forms bit-identical totals whatever its tile geometry.
+BB_DEV void bbp_consume_tgx(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par, unsigned epoch, int* ok) {
+    double* lds = cx.lds;
+    const int KK = M.K + 2 * M.nt1, KKP = (KK + 63) & ~63, chunks = A.world;
+    int NQ = cx.nthr / KKP;
+    if (NQ > chunks) NQ = chunks;
+    if (NQ < 1) NQ = 1;
+    const bb_gran* in = S.xgr[A.rank] + (long long)par * A.world * 8 * KK;
+    BB_PASS(cx, tid) {
+        int q = 0;
+        for (int t = KKP; t <= tid && q < NQ; t += KKP) ++q;             // (no integer division in the step loop)
+        const int kk = tid - q * KKP;
+        if (q < NQ) {
+            const bool act = kk < KK;
+            const int k = act ? kk : KK - 1;
+            for (int c = q; c < chunks; c += NQ) {
+                double v[8];
+                if (!bb_gran_poll8<true>(in, (unsigned)(c * 8 * KK + k), (unsigned)KK, 8, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[i];
+                if (act) lds[L.red + c * KKP + kk] = s;
+            }
+        }
+    }
+    BB_STAMP(cx, S, 1);
+    BB_SYNC(cx);
+    BB_PASS(cx, tid) {
+        if (tid < KK) {
+            double s = lds[L.red + tid];
+            for (int c = 1; c < chunks; ++c) s += lds[L.red + c * KKP + tid];
             if (tid < M.K) bb_put_total(M, L, lds, tid, s);
             else lds[L.zgl + (tid - M.K)] = s;
         }

@@ -193,7 +193,8 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     }
     L.acc = Y.racc + busy;
     L.acc_cap = xg_want;
-    L.red = o;     o += 2 * 128 + 4 * ((KK + 63) & ~63) + 16;          // (bbp_consume<.., WIDE> / bbp_consume_tg: the second half's partial sums)
+    { const int nch = xg_rows / 8 > 5 ? xg_rows / 8 : 5;               // (bbp_consume<.., WIDE> / bbp_consume_tg: the other thread groups' partial sums; bbp_consume_tgx: one chunk sum per source rank)
+      L.red = o;     o += 2 * 128 + nch * ((KK + 63) & ~63) + 16; }
     (void)lmax;
     L.total = Y.total = (o + 1) & ~1;
     return Y;
@@ -1248,7 +1249,7 @@ BB_DEV void br_xchg_lead(BBCtx& cx, const DevModel& M, const DevState& S, const 
     // (fetching the members' rows in one round trip -- two waves, 16 members each, partial sums through LDS -- measured SLOWER,
     //  as round 1 had found for k_persist: 7.6 k cycles against 4.8 k for the leader's read + sum + publish)
     if (cx.block < bbp_groups(A)) {
-        if (BR_TG) bbp_leader_reduce_tg<XG>(cx, M, S, A, (int)(xc & 1), epoch, ok_slot);
+        if (BR_TG) bbp_leader_reduce_tg<XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
         else bbp_leader_reduce<XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
     }
 }
@@ -1256,7 +1257,8 @@ template <int KIND, int P, bool XG, bool MS = false>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                             unsigned long long xc, int* ok_slot, bool want_el = false, int ring = 0, int smp = 0, int slot = -1) {
     const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
-    if (!XG && BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
+    if (XG && BR_TG) bbp_consume_tgx(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
+    else if (BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
     else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
     // pf = 3 (BB_TUNE_PF only): the window slot fetched HERE, behind the exchange and in front of the F pass and the first gradients.
     // Measured on C3 (no LDS room for pf = 1): 52.7k steps/s against 56.3k with pf = 0 -- the fetch is exposed, not hidden

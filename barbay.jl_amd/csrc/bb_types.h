@@ -99,6 +99,7 @@ struct DevState {
     // seen from here (r == own rank: the local inbox itself)
     double *xout[BB_MAX_WORLD];
     unsigned *xout_rdy[BB_MAX_WORLD];
+    struct bb_gran *xgr[BB_MAX_WORLD]; // k_res: the same group rows [2][world][8][K + 2 nt1] as self-validating 16-byte entries (no ready words; bb_persist.h)
 };
 
 #define BB_ELBO_RING 4096

@@ -65,7 +65,10 @@ def setup_p2p(engine) -> bool:
         ok = engine.p2p_enable(True)
     except BarBayHipError:
         ok = False
-    if not vote(ok):
+    # the two resident kernels speak different inbox protocols (k_res: tagged entries, k_persist: rows + ready words): every rank the same one
+    kinds = [None] * world
+    dist.all_gather_object(kinds, int(engine.stats()["resident_kernel"]) if ok else -1)
+    if not vote(ok and all(k == kinds[0] for k in kinds)):
         try:
             engine.p2p_enable(False)
         except BarBayHipError:
