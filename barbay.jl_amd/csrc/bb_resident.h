@@ -457,7 +457,9 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
         if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
         if (tid < M.Ttot) ((int*)(lds + Y.envt))[tid] = (KIND == 1 || KIND == 4) ? M.env_idx[tid] : 0;
     }
+    BB_STAMP_RT(cx, S, 7);          // (thread 0: the segment table is built)
     BB_SYNC(cx);
+    BB_STAMP_RT(cx, S, 8);
     BB_PASS(cx, tid) {
         // row j of the tile's moment row = sum over the threads of time-pair class k (tid % LPB == k) of their value v
         int* rm = (int*)(lds + Y.rowmap);
@@ -497,6 +499,7 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
             rt[0] = M.tcum[r]; rt[1] = Y.zr0[r]; rt[2] = M.T[r]; rt[3] = 0;
         }
     }
+    BB_STAMP_RT(cx, S, 9);          // (thread 0's share of the LDS tables)
 }
 
 template <int KIND, int P, bool AP = false>
@@ -525,6 +528,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
             st.a[k] = st.h[k] = st.z[k] = st.lam[k] = st.gp[k] = bb_d2{0.0, 0.0};
         }
     }
+    BB_STAMP_RT(cx, S, 10);         // (descriptors formed, state loads issued)
     BB_SYNC(cx);
 }
 

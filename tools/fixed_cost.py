@@ -30,5 +30,5 @@ if os.path.exists(st_lib) and not os.environ.get("NO_STAMPS"):
         s = e.stamps().astype(np.int64)
         t0 = s[:, 2].min()
         f = lambda col: f"{(np.median(s[:, col]) - t0) / 100:7.2f} (last tile {(s[:, col].max() - t0) / 100:7.2f})"
-        print(f"n {n:3d} stamped launch, us after the first tile's entry: all tiles entered {(s[:, 2].max() - t0) / 100:.2f}; prologue done {f(3)}; "
+        print(f"n {n:3d} stamped launch, us after the first tile's entry: all tiles entered {(s[:, 2].max() - t0) / 100:.2f}; segment table built {f(7)}; met {f(8)}; LDS tables {f(9)}; descriptors + loads issued {f(10)}; prologue done {f(3)}; "
               f"first normals drawn {f(4)}; loop done {f(5)}; epilogue done {f(6)}; kernel time {e.stats()['last_run_ms'] * 1e3:.1f}")
