@@ -24,6 +24,7 @@
 
 #ifdef BB_EMU
 #define BB_DEV static inline
+#define BB_HD static inline
 struct BBCtx { int nthr; int block; double* lds; const void* lay = nullptr; /* resident launch: its BBLds, precomputed */ };
 #define BB_PASS(cx, tid) for (int tid = 0; tid < (cx).nthr; ++tid)
 #define BB_SYNC(cx) ((void)0)
@@ -31,6 +32,7 @@ BB_DEV unsigned bb_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned
 #else
 #include <hip/hip_runtime.h>
 #define BB_DEV __device__ __forceinline__
+#define BB_HD __host__ __device__ __forceinline__      /* also called by the host engine (the tiles' tables are built there) */
 struct BBCtx { int nthr; int block; double* lds; const void* lay = nullptr; /* resident launch: its BBLds, precomputed */ };
 #define BB_PASS(cx, tid) for (int tid = threadIdx.x, _once = 1; _once; _once = 0)
 #define BB_SYNC(cx) __syncthreads()
@@ -194,7 +196,7 @@ struct BBTile {
     int NB;
 };
 
-BB_DEV BBTile bb_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
+BB_HD BBTile bb_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
     BBTile t;
     t.NB = NB;
     t.b0 = A.b_lo + (long long)block * NB;
@@ -240,9 +242,9 @@ enum BBSegKind {
 };
 struct BBSeg { long long lo, hi; int pbeg, blk, kind, ldsoff, r, pad; };   // 40 bytes = 5 doubles; pad = bb_hdelta of the segment
 // a segment's latents in a row of the TruncatedADAGrad window: entry = flat index - delta (DevModel.Dh)
-BB_DEV long long bb_hdelta(const DevModel& M, int blk, int r) { return blk == BK_L ? M.hdl[r] : M.hd0[blk] + (long long)r * M.hd1[blk]; }
+BB_HD long long bb_hdelta(const DevModel& M, int blk, int r) { return blk == BK_L ? M.hdl[r] : M.hd0[blk] + (long long)r * M.hd1[blk]; }
 
-BB_DEV int bb_seg_pairs(long long lo, long long hi) { return hi > lo ? (int)(((hi - 1) >> 1) - (lo >> 1) + 1) : 0; }
+BB_HD int bb_seg_pairs(long long lo, long long hi) { return hi > lo ? (int)(((hi - 1) >> 1) - (lo >> 1) + 1) : 0; }
 
 // Built by one thread; returns the number of segments, sg[n].pbeg = total pairs.
 template <int KIND>

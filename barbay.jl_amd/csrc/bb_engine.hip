@@ -238,6 +238,9 @@ struct bb_handle {
     // cross-GPU leg of the resident launch (bb_p2p_*)
     void* p2p_inbox = nullptr;               // this rank's inbox (fine-grained device memory)
     size_t p2p_rows_bytes = 0, p2p_bytes = 0, p2p_gran_off = 0;
+    double* d_segtab = nullptr;        // host-built tables of the resident launches (host_tables)
+    int* d_ldstab = nullptr;
+    size_t segtab_cap = 0, ldstab_cap = 0;
     void* p2p_peer[BB_MAX_WORLD] = {};       // peers' inboxes as mapped here
     bool p2p_ready = false, p2p_on = false;
     unsigned p2p_seq = 0;                    // probe sequence number (tokens only ever grow)
@@ -548,6 +551,56 @@ static bool build_geno_tiles(const bb_handle* h, int NB, int NBL, std::vector<lo
 // time points, the fifth model): they are 1 - 5 % SLOWER than k_persist -- parity is a run-time property of every pair there,
 // 45 spilled registers and two Philox draws in divergent lanes -- so setup_persistent asks for them only where k_persist cannot
 // run: the genotype model (whose other choice is the two-kernel step) or after k_persist has refused the shape.
+// The tables a tile of k_res / k_stream needs before its first step, built HERE instead of in every launch's prologue (where
+// thread 0 of each tile spent 3.4 us on its segment table behind a chain of scalar loads, and the per-lane descriptor loads of the
+// LDS tables another 1.8 us -- profiles/r03z_round3_final/fixed_cost.txt): per tile its segment table (br_build_segs, the same code),
+// once the tile-independent LDS tables (br_table_*).  BB_NO_HOST_TABLES=1: the kernels build them (A/B).
+template <int KIND>
+static void host_tables_kind(bb_handle* h, const RunArgs& A, const DevState& Sh, int nblk, int stride, std::vector<double>& tab) {
+    for (int b = 0; b < nblk; ++b) {
+        const BBTile t = KIND == 2 ? br_tile_geno(h->M, Sh, b, h->res_NB) : br_tile(h->M, A, b, h->res_NB);
+        const int g0 = KIND == 2 ? Sh.tile_g[b] : 0, g1 = KIND == 2 ? Sh.tile_g[b + 1] : 0;
+        double* rec = tab.data() + (size_t)b * stride;
+        const int n = br_build_segs<KIND>((BRSeg*)rec, h->M, h->Yh, t, b == 0, g0, g1);
+        ((int*)(rec + stride - 1))[0] = n;
+    }
+}
+static bool host_tables(bb_handle* h, const std::vector<long long>& tb, const std::vector<int>& tg) {
+    h->S.segtab = nullptr;
+    h->S.ldstab = nullptr;
+    h->S.segtab_stride = 0;
+    const char* ev = getenv("BB_NO_HOST_TABLES");
+    if (ev && atoi(ev) > 0) return true;
+    const DevModel& M = h->M;
+    const int nblk = h->res_nblk, stride = BR_SEG_DOUBLES * (4 + 4 * M.R + 1) + 1;
+    RunArgs A = make_args(h, 0, 0, 1, true, false);
+    A.nblk = nblk; A.nbl = h->res_NBL; A.ng = h->res_ng;
+    DevState Sh = h->S;
+    Sh.tile_b = tb.data();
+    Sh.tile_g = tg.data();
+    std::vector<double> tab((size_t)nblk * stride, 0.0);
+    switch (M.kind) {
+    case 0: host_tables_kind<0>(h, A, Sh, nblk, stride, tab); break;
+    case 1: host_tables_kind<1>(h, A, Sh, nblk, stride, tab); break;
+    case 2: host_tables_kind<2>(h, A, Sh, nblk, stride, tab); break;
+    case 3: host_tables_kind<3>(h, A, Sh, nblk, stride, tab); break;
+    default: host_tables_kind<4>(h, A, Sh, nblk, stride, tab);
+    }
+    const int K = M.K, Tt = M.Ttot, R = M.R;
+    std::vector<int> img((size_t)3 * K + 4 * Tt + 4 * R + 4, 0);
+    for (int j = 0; j < K; ++j) br_table_row(M, h->Yh, j, &img[2 * j], &img[2 * K + j]);
+    for (int j = 0; j < Tt; ++j) br_table_time(M, h->Yh.L, j, &img[3 * K + 4 * j]);
+    for (int r = 0; r < R; ++r) br_table_rep(M, h->Yh, r, &img[3 * K + 4 * Tt + 4 * r]);
+    // (the handle keeps one buffer of each, sized for the largest tile map it has seen)
+    if (tab.size() > h->segtab_cap) { double* d = nullptr; if (dalloc(h, &d, tab.size())) return false; h->d_segtab = d; h->segtab_cap = tab.size(); }
+    if (img.size() > h->ldstab_cap) { int* d = nullptr; if (dalloc(h, &d, img.size())) return false; h->d_ldstab = d; h->ldstab_cap = img.size(); }
+    if (h2d(h->d_segtab, tab.data(), tab.size() * 8, h->stream) || h2d(h->d_ldstab, img.data(), img.size() * 4, h->stream)) return false;
+    h->S.segtab = h->d_segtab;
+    h->S.segtab_stride = stride;
+    h->S.ldstab = h->d_ldstab;
+    return true;
+}
+
 static bool try_resident(bb_handle* h, bool any_parity) {
     const char* ev = getenv("BB_NO_RES");
     if (ev && atoi(ev) > 0) return false;
@@ -659,6 +712,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     h->res_pf = pf;
     h->res_stream = stream;
     h->lds_doubles_p = (size_t)Y.total;
+    if (!host_tables(h, tb, tg)) { h->res_P = 0; return false; }
     return true;
 }
 

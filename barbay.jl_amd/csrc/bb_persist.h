@@ -311,7 +311,7 @@ BB_DEV void bbp_prefetch_slot(BBCtx& cx, const DevModel& M, const DevState& S, c
 typedef unsigned long long bb_u64;
 
 #define BB_NG_MAX 32       /* groups of the exchange's first hop: RunArgs.ng = 8 (the cross-GPU inbox protocol is laid out for 8), 16, or -- self-validating rows only -- 32 */
-BB_DEV int bbp_groups(const RunArgs& A) { return A.nblk < A.ng ? A.nblk : A.ng; }
+BB_HD int bbp_groups(const RunArgs& A) { return A.nblk < A.ng ? A.nblk : A.ng; }
 
 // Poll *word until it equals epoch; false = gave up (timeout word set).
 BB_DEV bool bb_wait_word(const unsigned* word, unsigned epoch, unsigned* tmo, unsigned limit) {

@@ -270,7 +270,7 @@ template <bool AP> BB_DEV void br_store_pair(double* base, long long i0, bool a0
 // Tile map of k_res.  The group leaders of the exchange (tiles 0 .. 7) do extra work between their publish and everybody's
 // consume; with nbl < NB barcodes they reach their publish early enough to have drawn their next normals before their members'
 // rows arrive, and the group rows appear one draw (~5 k cycles) sooner for all tiles.
-BB_DEV BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
+BB_HD BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
     if (A.nbl <= 0) return bb_tile(M, A, block, NB);
     const int nlead = bbp_groups(A);
     BBTile t;
@@ -291,7 +291,7 @@ BB_DEV BBTile br_tile(const DevModel& M, const RunArgs& A, int block, int NB) {
 // that a tile holds ALL mutants of the genotypes [tile_g[i], tile_g[i + 1]) it owns: d/dtheta_g = sum over the genotype's mutants
 // of w As is then a sum inside the tile, and theta_g is sampled, staged and updated by that tile alone
 // (/root/reference/src/model_fitness_normal_hierarchical_genotypes.jl:209-243: s_eff = theta[geno] + exp(logtau) theta_tilde).
-BB_DEV BBTile br_tile_geno(const DevModel& M, const DevState& S, int block, int NB) {
+BB_HD BBTile br_tile_geno(const DevModel& M, const DevState& S, int block, int NB) {
     BBTile t;
     t.NB = NB;
     t.b0 = S.tile_b[block];
@@ -305,7 +305,7 @@ BB_DEV BBTile br_tile_geno(const DevModel& M, const DevState& S, int block, int 
 
 // ---- segment table of a tile in the padded thread-index space (one thread) --------------------------------------
 template <int KIND>
-BB_DEV int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTile& t, bool globals, int g0 = 0, int g1 = 0) {
+BB_HD int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTile& t, bool globals, int g0 = 0, int g1 = 0) {
     int n = 0, cur = 0;
     auto add = [&](int blk, int kind, long long lo, long long cnt, int ldsoff, int r, int lpb, int T) {
         if (cnt <= 0) return;
@@ -439,6 +439,40 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
 // ---- tile setup shared by k_res and k_stream: segment table, zeroed LDS tables, row map, F-pass table (ends inside a pass: the caller
 // meets at a barrier before anything reads them).  ncol: column entries per time-pair class in the transposed contributions
 // (k_res: the tile's barcodes; k_stream: the rows of 16 lanes)
+// ---- the tile-independent LDS descriptor tables, one entry each (device: a thread per entry; host: host_tables) ----------------
+// row j of a tile's moment row = sum over the threads of time-pair class k (tid % LPB == k) of their value v: everything the row sums
+// need in ONE LDS read {lanes per barcode | used << 24, column's LDS offset} -- looked up by replicate in the layout record they were
+// three dependent vector loads from device memory behind the code's LDS read, in a pass that is all latency; tmap[j] = the time point
+// whose normaliser S_t row entry j is, or -1
+BB_HD void br_table_row(const DevModel& M, const BRLay& Y, int j, int* rm2, int* tmapj) {
+    int code = 0, col = 0;
+    for (int r = 0; r < M.R; ++r) {
+        const int T = M.T[r], q0 = j - M.kq[r];
+        if (q0 < 0 || q0 >= 6 * T - 5) continue;
+        int tt, q;
+        if (q0 < T) { tt = q0; q = 0; } else { tt = (q0 - T) / 5; q = 1 + (q0 - T) - 5 * tt; }
+        code = Y.lpb[r] | (1 << 24);
+        col = Y.racc_r[r] + ((tt & 1) * 6 + q) * (Y.rw[r] + 4) + (tt >> 1);
+    }
+    rm2[0] = code;
+    rm2[1] = col;
+    int tj = -1;
+    for (int r = 0; r < M.R; ++r) { const int tt = j - M.kq[r]; if (tt >= 0 && tt < M.T[r]) tj = M.tcum[r] + tt; }
+    *tmapj = tj;
+}
+// F-pass table: a lane of the F pass looked its replicate up in the model record -- a chain of four dependent vector loads from
+// device memory (~2 k cycles) in a pass the whole tile waits for
+BB_HD void br_table_time(const DevModel& M, const BBLds& L, int j, int* ft) {
+    int r = 0;
+    while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
+    const int tt = j - M.tcum[r], T = M.T[r];
+    ft[0] = tt < T - 1 ? L.wk + M.kq[r] + T + 5 * tt : -1;
+    ft[1] = M.off_t[r] + tt;
+    ft[2] = tt > 0 ? 1 : 0;
+    ft[3] = 0;
+}
+BB_HD void br_table_rep(const DevModel& M, const BRLay& Y, int r, int* rt) { rt[0] = M.tcum[r]; rt[1] = Y.zr0[r]; rt[2] = M.T[r]; rt[3] = 0; }
+
 template <int KIND>
 BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int ncol_or_neg) {
     double* lds = cx.lds;
@@ -450,7 +484,14 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
     const int KK = M.K + 2 * M.nt1;
     BB_PASS(cx, tid) {
         // li[1] = exchange ok word; it starts at 0 ("leave") while an earlier launch's timeout is unacknowledged by the host
-        if (tid == 0) { li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0, g0, g1); li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = ncol_or_neg < 0 ? t.nbt : ncol_or_neg; }
+        if (S.segtab) {
+            // the tile's segment table came from the host (thread 0 building it here took 3.4 us of every launch): one coalesced copy
+            const double* src = S.segtab + (long long)cx.block * S.segtab_stride;
+            const int nd = S.segtab_stride - 1;
+            for (int i = tid; i < nd; i += cx.nthr) lds[Y.seg + i] = src[i];
+            if (tid == 0) li[0] = ((const int*)(src + nd))[0];
+        } else if (tid == 0) li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0, g0, g1);
+        if (tid == 0) { li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = ncol_or_neg < 0 ? t.nbt : ncol_or_neg; }
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
         for (int i = tid; i < Y.zlw * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
         for (int i = tid; i < Y.nst * Y.stw; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
@@ -460,43 +501,21 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
     BB_STAMP_RT(cx, S, 7);          // (thread 0: the segment table is built)
     BB_SYNC(cx);
     BB_STAMP_RT(cx, S, 8);
-    BB_PASS(cx, tid) {
-        // row j of the tile's moment row = sum over the threads of time-pair class k (tid % LPB == k) of their value v
-        int* rm = (int*)(lds + Y.rowmap);
-        const int nseg = li[0];
-        for (int j = tid; j < M.K; j += cx.nthr) {
-            int code = 0, col = 0;
-            for (int r = 0; r < M.R; ++r) {
-                const int T = M.T[r], q0 = j - M.kq[r];
-                if (q0 < 0 || q0 >= 6 * T - 5) continue;
-                int tt, q;
-                if (q0 < T) { tt = q0; q = 0; } else { tt = (q0 - T) / 5; q = 1 + (q0 - T) - 5 * tt; }
-                // (everything the row sums need in ONE LDS read: looked up by replicate in the layout record they were three dependent
-                //  vector loads from device memory behind the code's LDS read, in a pass that is all latency)
-                code = Y.lpb[r] | (1 << 24);
-                col = Y.racc_r[r] + ((tt & 1) * 6 + q) * (Y.rw[r] + 4) + (tt >> 1);
-            }
-            rm[2 * j] = code;
-            rm[2 * j + 1] = col;
-            int tj = -1;
-            for (int r = 0; r < M.R; ++r) { const int tt = j - M.kq[r]; if (tt >= 0 && tt < M.T[r]) tj = M.tcum[r] + tt; }
-            ((int*)(lds + L.tmap))[j] = tj;
+    int* rm = (int*)(lds + Y.rowmap);
+    if (S.ldstab) {
+        // the tables are the same for every tile: built once on the host, one coalesced copy here
+        const int K = M.K, Tt = M.Ttot, R = M.R;
+        BB_PASS(cx, tid) {
+            for (int i = tid; i < 2 * K; i += cx.nthr) rm[i] = S.ldstab[i];
+            for (int i = tid; i < K; i += cx.nthr) ((int*)(lds + L.tmap))[i] = S.ldstab[2 * K + i];
+            for (int i = tid; i < 4 * Tt; i += cx.nthr) ((int*)(lds + Y.ftab))[i] = S.ldstab[3 * K + i];
+            for (int i = tid; i < 4 * R; i += cx.nthr) ((int*)(lds + Y.rtab))[i] = S.ldstab[3 * K + 4 * Tt + i];
         }
-        // F-pass table: a lane of the F pass looked its replicate up in the model record -- a chain of four dependent vector loads from
-        // device memory (~2 k cycles) in a pass the whole tile waits for
-        for (int j = tid; j < M.Ttot; j += cx.nthr) {
-            int r = 0;
-            while (r + 1 < M.R && j >= M.tcum[r + 1]) ++r;
-            const int tt = j - M.tcum[r], T = M.T[r];
-            int* ft = (int*)(lds + Y.ftab) + 4 * j;
-            ft[0] = tt < T - 1 ? L.wk + M.kq[r] + T + 5 * tt : -1;
-            ft[1] = M.off_t[r] + tt;
-            ft[2] = tt > 0 ? 1 : 0;
-            ft[3] = 0;
-        }
-        for (int r = tid; r < M.R; r += cx.nthr) {
-            int* rt = (int*)(lds + Y.rtab) + 4 * r;
-            rt[0] = M.tcum[r]; rt[1] = Y.zr0[r]; rt[2] = M.T[r]; rt[3] = 0;
+    } else {
+        BB_PASS(cx, tid) {
+            for (int j = tid; j < M.K; j += cx.nthr) br_table_row(M, Y, j, rm + 2 * j, (int*)(lds + L.tmap) + j);
+            for (int j = tid; j < M.Ttot; j += cx.nthr) br_table_time(M, L, j, (int*)(lds + Y.ftab) + 4 * j);
+            for (int rr = tid; rr < M.R; rr += cx.nthr) br_table_rep(M, Y, rr, (int*)(lds + Y.rtab) + 4 * rr);
         }
     }
     BB_STAMP_RT(cx, S, 9);          // (thread 0's share of the LDS tables)

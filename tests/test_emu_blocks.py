@@ -89,6 +89,23 @@ def test_owner_computes_launch_equals_two_kernel(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name", ["fitness_T6", "multienv_T8", "replicate_R3", "multienv_replicate_T6", "genotype_runs"])
+def test_host_built_tables_equal_the_kernels_own(emu_lib, monkeypatch, name):
+    """The tiles' segment tables and the LDS descriptor tables come from the host (bb_engine.hip, host_tables); BB_NO_HOST_TABLES=1
+    makes every tile build them in its prologue, as before: the runs must agree bit for bit."""
+    import numpy as np
+    from conftest import make_engine
+    sp = c.synth(name, seed=4)
+    outs = []
+    for no in ("0", "1"):
+        monkeypatch.setenv("BB_NO_HOST_TABLES", no)
+        with make_engine(sp, emu_lib, seed=5, window=4, launch_mode=2) as e:
+            assert e.stats()["resident_kernel"] == 2
+            e.run(6)
+            outs.append(e.get_params())
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
 @pytest.mark.parametrize("nb,nthr", [(100, 256), (24, 128), (150, 512), (40, 128), (9, 64)])
 def test_owner_computes_launch_geometries(emu_lib, monkeypatch, nb, nthr):
     """several pair slots per thread, tiles that end inside a wave, neutral / mutant boundary inside a tile"""
