@@ -242,6 +242,9 @@ template <bool AP> BB_DEV bb_d2 br_load_pair(const double* base, long long i0, b
 #ifndef BR_PUB_COALESCED
 #define BR_PUB_COALESCED 1
 #endif
+#ifndef BR_SKIP_EXP
+#define BR_SKIP_EXP 1
+#endif
 #ifndef BR_NT_STORE
 #define BR_NT_STORE 1
 #endif
@@ -669,6 +672,12 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             // loglambda: lambda = e^z; logsigma_bc: precision w = e^{-2 z}; (others: unused)
             const int kd = st.meta[k] & 15;
             const double f = (kd == SK_LS_E || (KIND >= 2 && kd == SK_LS_R)) ? -2.0 : 1.0;      // logtau: e^{logtau}
+#if BR_SKIP_EXP && !defined(BB_EMU)
+            // a wave whose pairs are all s_bc / theta / theta_tilde -- nobody reads their e^z -- skips the chain (C2
+            // 83.9 -> 84.7 k steps/s, C4 and C3 unchanged: profiles/r03g_parallel_leaders/skip_unused_exp.txt)
+            if (__builtin_amdgcn_ballot_w64((st.meta[k] & BRM_VALID) && (kd == SK_L || (kd < SK_GS && br_stage_trn<KIND>(kd) >= 0))) == 0ull) st.lam[k] = bb_d2{0.0, 0.0};
+            else
+#endif
             st.lam[k] = bb_d2{bb_exp(f * st.z[k].x), bb_exp(f * st.z[k].y)};
             BR_SCHED_FENCE();
             if (MS && want_el && (st.meta[k] & BRM_VALID)) {
