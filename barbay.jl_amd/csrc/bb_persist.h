@@ -442,8 +442,6 @@ BB_DEV bool bb_gran_poll8(const bb_gran* base, unsigned off, unsigned stride, in
 }
 
 BB_DEV long long bbx_slot(const RunArgs& A, int par, int src, int g);
-BB_DEV void bb_st_sys(double* p, double v);
-BB_DEV void bb_set_word_sys(unsigned* word, unsigned v);
 // leader of group g = tile g: its members' rows (16 at most per batch of two polls), summed in member order, out as the group row.
 // XG: the first hop is the same (the members are this rank's own tiles); the group row then goes into EVERY rank's inbox as
 // tagged entries written with system-scope stores (bb_gran_st<true>): no drain, no meet, no ready words on the cross-GPU hop either.
@@ -489,7 +487,8 @@ BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S
                 else bb_gran_st(S.gxrow + ((long long)par * NG + g) * KK + tid, s, epoch);
             }
         }
-        BB_SYNC(cx);          // (the chunk sums' LDS is the consume's as well)
+        BB_SYNC(cx);          // (the chunk sums' LDS is the consume's as well; with separate regions and no barrier here C2 ran 1 % SLOWER:
+                              //  the leader's other waves running ahead slow the chain everybody waits for -- as round 1 found for k_persist)
         BB_STAMP(cx, S, 18);
         return;
     }

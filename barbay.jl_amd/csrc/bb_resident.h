@@ -172,7 +172,9 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     // Staging of the cross-GPU inbox rows (bbp_consume<true>; xg_rows = 8 x world rows of KK entries, summed in chunks of whole rows):
     // in use between the publish and the F pass, while the drawn-ahead normals (and, pf = 0, the window slot) wait in the transient
     // region -- whatever that region has to spare behind them is the staging; only the missing part is added.
-    const int xg_want = xg_rows > 0 ? (xg_rows * KK < (BB_NQ + 1) * NT ? xg_rows * KK : (BB_NQ + 1) * NT) : 0;
+    // (Only the ready-word form of the cross-GPU consume stages rows, bbp_consume<true>: builds with BR_TG = 0.  The tagged form polls
+    //  the inbox straight into registers, bbp_consume_tgx.)
+    const int xg_want = (!BR_TG && xg_rows > 0) ? (xg_rows * KK < (BB_NQ + 1) * NT ? xg_rows * KK : (BB_NQ + 1) * NT) : 0;
     int busy;           // doubles of the transient region alive during the exchange
     if (stream) {
         Y.hbuf = Y.eps = Y.racc;         // (neither exists: normals and window slots go through registers)
