@@ -28,7 +28,7 @@ def newest(pattern):
 
 for src, dst in ((f"{tag}_bench.json", "bench.json"), (f"{tag}_bench20.json", "bench_20_steps_warmup_5.json"), (f"{tag}_rehearsal2.json", "bench_2ranks_one_gpu_rehearsal.json"),
                  (f"{tag}_c2_eighth.json", "bench_6250_barcodes.json"), (f"{tag}/configs.txt", "configs.txt"), (f"{tag}/fixed_cost.txt", "fixed_cost.txt"),
-                 (f"{tag}/stamps.txt", "stamps.txt"), (f"{tag}/hbm_traffic.json", "hbm_traffic.json"), (f"{tag}_hbm_traffic_C5.json", "hbm_traffic_C5_k_stream.json"),
+                 (f"{tag}/stamps.txt", "stamps.txt"), (f"{tag}/hbm_traffic.json", "hbm_traffic.json"), (f"{tag}_hbm_traffic_C5.json", "hbm_traffic_C5_k_stream.json"), (f"{tag}_hbm_traffic_C3.json", "hbm_traffic_C3.json"), (f"{tag}_hbm_traffic_C4.json", "hbm_traffic_C4.json"),
                  (f"{tag}_mix.txt", "pmc_instruction_mix.txt"), (f"{tag}_waves.txt", "per_wave_stamps.txt"), (f"{tag}_window_accuracy.txt", "window_accuracy.txt"),
                  (f"{tag}_validate_c2.json", "validate_c2_10000_iterations.json"), (f"{tag}_p2p_rehearsal.txt", "p2p_rehearsal_one_gpu.txt"),
                  (f"{tag}_ms_rates.txt", "ms_rates.txt"), (f"{tag}_tests.log", "gpu_tests.log")):

@@ -12,6 +12,12 @@ done
 (cd /tmp && CFG=C5 STEPS=1000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$O/${TAG}_pmcf_C5 -- python3 $ROOT/tools/kernel_trace_config.py) > $O/${TAG}_pmcf_C5.log 2>&1
 (cd /tmp && CFG=C5 STEPS=1000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$O/${TAG}_pmcw_C5 -- python3 $ROOT/tools/kernel_trace_config.py) > $O/${TAG}_pmcw_C5.log 2>&1
 python3 tools/hbm_traffic.py $O/${TAG}_pmcf_C5 $O/${TAG}_pmcw_C5 k_stream 1000 "profiles/$TAG C5 on one GPU" $O/${TAG}_hbm_traffic_C5.json > /dev/null 2>&1
+# ... and of C3 / C4 (k_res: only the window slot should reach the memory side)
+for CFG in C3 C4; do
+  (cd /tmp && CFG=$CFG STEPS=4000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$O/${TAG}_pmcf_$CFG -- python3 $ROOT/tools/kernel_trace_config.py) > $O/${TAG}_pmcf_$CFG.log 2>&1
+  (cd /tmp && CFG=$CFG STEPS=4000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$O/${TAG}_pmcw_$CFG -- python3 $ROOT/tools/kernel_trace_config.py) > $O/${TAG}_pmcw_$CFG.log 2>&1
+  python3 tools/hbm_traffic.py $O/${TAG}_pmcf_$CFG $O/${TAG}_pmcw_$CFG k_res 4000 "profiles/$TAG $CFG" $O/${TAG}_hbm_traffic_$CFG.json > /dev/null 2>&1
+done
 for CFG in C3 C4 C5rank; do CFG=$CFG timeout -k 10 300 python tools/validate_c2.py 3000 > $O/${TAG}_validate_$CFG.json 2>/dev/null; done
 (WL=c2 timeout -k 10 200 python tools/p2p_rehearsal.py 2 2000 && WL=c2 timeout -k 10 200 python tools/p2p_rehearsal.py 4 2000 && WL=c4 timeout -k 10 200 python tools/p2p_rehearsal.py 4 2000 && WL=c5 SHAPE_W=8 timeout -k 10 200 python tools/p2p_rehearsal.py 4 1000 && WL=c2r SHAPE_W=8 timeout -k 10 200 python tools/p2p_rehearsal.py 4 2000) 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo\|peer ranks" > $O/${TAG}_p2p_rehearsal.txt
 timeout -k 10 200 python tools/ms_rates.py 2>&1 | grep -v amdgpu > $O/${TAG}_ms_rates.txt
