@@ -565,7 +565,14 @@ static inline
 #else
 __device__ __attribute__((noinline))
 #endif
-void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsigned step, unsigned stream, BRIdx<P> ix) {
+void br_draw_call(bb_d2* eps, int nthr, int tid, unsigned long long seed, unsigned step, unsigned stream,
+                  long long i0a, long long i0b, long long i0c, long long i0d, int ma, int mb, int mc, int md) {
+    // (the pair indices as scalar arguments: a struct of three or four of them went through scratch memory at every call -- C3's
+    //  instance wrote and re-read 36 B per thread and step, 4 MB of the 21.9 MB the counters saw)
+    BRIdx<P> ix;
+    { const long long i0v[4] = {i0a, i0b, i0c, i0d}; const int mv[4] = {ma, mb, mc, md};
+#pragma unroll
+      for (int k = 0; k < P; ++k) { ix.i0[k] = i0v[k]; ix.meta[k] = mv[k]; } }
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         if (!(ix.meta[k] & BRM_VALID)) continue;
@@ -591,10 +598,9 @@ BB_DEV void br_draw_ahead(BBCtx& cx, const RunArgs& A, const BRLay& Y, BRSt<P>* 
     bb_d2* eps = (bb_d2*)(cx.lds + Y.eps);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
-        BRIdx<P> ix;
-#pragma unroll
-        for (int k = 0; k < P; ++k) { ix.i0[k] = st.i0[k]; ix.meta[k] = st.meta[k]; }
-        br_draw_call<P, AP>(eps, cx.nthr, tid, A.seed, (unsigned)step, stream, ix);
+        static_assert(P <= 4, "br_draw_call takes four pair slots");
+        br_draw_call<P, AP>(eps, cx.nthr, tid, A.seed, (unsigned)step, stream, st.i0[0], P > 1 ? st.i0[P > 1 ? 1 : 0] : 0, P > 2 ? st.i0[P > 2 ? 2 : 0] : 0,
+                            P > 3 ? st.i0[P > 3 ? 3 : 0] : 0, st.meta[0], P > 1 ? st.meta[P > 1 ? 1 : 0] : 0, P > 2 ? st.meta[P > 2 ? 2 : 0] : 0, P > 3 ? st.meta[P > 3 ? 3 : 0] : 0);
     }
 }
 
