@@ -73,6 +73,9 @@ struct BRLay {
                          // time point), its index inside s_pop, has a time point before it, -}
     int envt;            // [Ttot] ints: environment of every time point (multienv)
     int gas;             // genotype model: [SU] w As of every mutant of the tile, summed per genotype by the theta threads
+    int gix;             // genotype model: int tables of the tile -- [SU] genotype of every mutant minus the tile's first, then [SU] per own genotype
+                         // first local mutant | members << 16: k_stream forms its pair descriptors in every pass, and looked these up in device memory
+                         // (two or three dependent loads per slot and pass)
     int seg;             // BRSeg table
     int total;
     int lpb[BB_MAX_REP];
@@ -151,9 +154,10 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     Y.csum = o;    o += BB_MAX_REP;
     o = (o + 1) & ~1;
     Y.ftab = o;    o += 2 * M.Ttot;
-    Y.rtab = o;    o += 2 * M.R;
+    Y.rtab = o;    o += 2 * M.R;          // [R] {tcum, zr0, T, cnt_off (or -1: beyond 31 bits, read from the model record)}
     Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
     Y.gas = o;     o += M.kind == 2 ? Y.SU : 0;
+    Y.gix = o;     o += M.kind == 2 ? Y.SU + 1 : 0;
     Y.seg = o;     o += BR_SEG_DOUBLES * (4 + 4 * M.R + 1);      // (br_build_segs: at most R + 1 + 3 R + 2 segments, + the end marker)
     L.seg = Y.seg;
     o = (o + 1) & ~1;
@@ -361,7 +365,10 @@ BB_HD int br_build_segs(BRSeg* sg, const DevModel& M, const BRLay& Y, const BBTi
 // (LPBC > 0: the lanes per barcode as a compile-time constant -- k_stream recomputes descriptors per pass and a run-time integer
 //  division costs ~30 instructions; CNT = false: the pair's counts are not fetched)
 template <int KIND, int P, bool AP = false, int LPBC = 0, bool CNT = true>
-BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int nseg, int g0, int g1, int p, BRSt<P>& st, int k) {
+BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int nseg, int g0, int g1, int p, BRSt<P>& st, int k, const double* lds) {
+    const int* gx = (const int*)(lds + Y.gix);          // (genotype model: the tile's genotype tables, br_tile_setup)
+    const int* rtb = (const int*)(lds + Y.rtab);        // per replicate {tcum, zr0, T, cnt_off}: by lane-indexed loads from the model record these
+    const int* envt = (const int*)(lds + Y.envt);       // were dependent vector loads from device memory in front of everything else
     const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
     int si = -1;
     for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
@@ -380,7 +387,7 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
                 i0 = s.lo + (long long)bl * s.T + t0;
                 meta |= BRM_A0 | (t0 + 1 < s.T ? BRM_A1 : 0) | BRM_VALID | (t0 > 0 ? BRM_PREV : 0) | (t0 + 2 < s.T ? BRM_NEXT : 0);   // (odd T: the last lane owns one latent)
                 st.zoff[k] = s.ldsoff + bl * (s.T + 1) + t0;
-                st.pt[k] = M.tcum[s.r] + t0;
+                st.pt[k] = rtb[4 * s.r] + t0;
                 if (bl >= t.nshift) {
                     meta |= BRM_MUT;
                     const int ml = bl - t.nshift;
@@ -388,15 +395,16 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
                     // multienv_replicate: (r NB + ml) E + e -- for the differences t0-1, t0, t0+1 (environment of t + 1)
                     const int base = KIND >= 3 ? (s.r * t.NB + ml) * E : ml * E;
                     // (genotype model: unit ml, theta index = its genotype's position among the tile's own = ml - thoff)
-                    st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : (KIND == 2 ? ml - (M.geno_idx[t.m0 + ml] - g0) : 0);
+                    st.thoff[k] = KIND >= 3 ? s.r * t.NB * E : (KIND == 2 ? ml - gx[ml] : 0);
                     for (int d = 0; d < 3; ++d) {
                         const int tt = t0 - 1 + d;
-                        const int e = (E > 1 && tt >= 0 && tt < s.T - 1) ? M.env_idx[M.tcum[s.r] + tt + 1] : 0;
+                        const int e = (E > 1 && tt >= 0 && tt < s.T - 1) ? envt[rtb[4 * s.r] + tt + 1] : 0;
                         st.uo[k][d] = base + e;
                     }
                 }
                 if (CNT) {
-                    const long long cb = M.cnt_off[s.r] + t.b0 * s.T + (long long)bl * s.T + t0;
+                    const int co = rtb[4 * s.r + 3];
+                    const long long cb = (co >= 0 ? (long long)co : M.cnt_off[s.r]) + t.b0 * s.T + (long long)bl * s.T + t0;
                     st.cnt[k][0] = M.counts[cb];
                     st.cnt[k][1] = t0 + 1 < s.T ? M.counts[cb + 1] : 0u;
                 }
@@ -411,13 +419,17 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
             if (KIND == 2 && s.kind == SK_TH_R) {
                 // theta of genotype g: its mutants are the consecutive local units [first, first + n) -- uo[x] = first | n << 16
                 for (int x = 0; x < 2; ++x) {
-                    const long long g = g0 + (i0 - s.lo) + x;
-                    int first = 0, n = 0;
-                    if (g >= g0 && g < g1) {
-                        n = M.geno_ptr[g + 1] - M.geno_ptr[g];
-                        if (n > 0) first = (int)(M.geno_mem[M.geno_ptr[g]] - t.m0);
+                    const long long gl = (i0 - s.lo) + x;             // (own genotype number gl of the tile's g1 - g0)
+                    int v = 0;
+                    if (gl >= 0 && gl < g1 - g0) {
+                        if (gl < Y.SU) v = gx[Y.SU + (int)gl];
+                        else {          // (more own genotypes than the table holds -- genotypes without mutants: from device memory)
+                            const long long g = g0 + gl;
+                            const int n = M.geno_ptr[g + 1] - M.geno_ptr[g];
+                            v = (n > 0 ? (int)(M.geno_mem[M.geno_ptr[g]] - t.m0) : 0) | (n << 16);
+                        }
                     }
-                    st.uo[k][x] = first | (n << 16);
+                    st.uo[k][x] = v;
                 }
             } else if (s.kind < SK_GS) {
                 // unit (ml, e) of latent x: index j = (i0 - lo) + x = ml * E + e inside the segment; its barcode's local index
@@ -428,7 +440,7 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
                     const int ml = j / E, e = j - ml * E;
                     st.uo[k][x] = t.nshift + ml;
                     // (genotype model, E == 1: the unit's theta index instead of its environment, 16 bits each)
-                    if (KIND == 2) env |= ((j < t.nmt ? M.geno_idx[t.m0 + j] - g0 : 0) & 0xffff) << (16 * x);
+                    if (KIND == 2) env |= ((j < t.nmt ? gx[j] : 0) & 0xffff) << (16 * x);
                     else env |= e << (8 * x);
                 }
                 st.uo[k][2] = env;
@@ -476,7 +488,10 @@ BB_HD void br_table_time(const DevModel& M, const BBLds& L, int j, int* ft) {
     ft[2] = tt > 0 ? 1 : 0;
     ft[3] = 0;
 }
-BB_HD void br_table_rep(const DevModel& M, const BRLay& Y, int r, int* rt) { rt[0] = M.tcum[r]; rt[1] = Y.zr0[r]; rt[2] = M.T[r]; rt[3] = 0; }
+BB_HD void br_table_rep(const DevModel& M, const BRLay& Y, int r, int* rt) {
+    rt[0] = M.tcum[r]; rt[1] = Y.zr0[r]; rt[2] = M.T[r];
+    rt[3] = M.cnt_off[r] < (1ll << 31) ? (int)M.cnt_off[r] : -1;          // (first count of the replicate)
+}
 
 template <int KIND>
 BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int ncol_or_neg) {
@@ -502,6 +517,17 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
         for (int i = tid; i < Y.nst * Y.stw; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
         if (tid <= M.Ttot) { lds[L.cc + tid] = 0.0; lds[L.wbar + tid] = 0.0; lds[L.Dt + tid] = 0.0; }
         if (tid < M.Ttot) ((int*)(lds + Y.envt))[tid] = (KIND == 1 || KIND == 4) ? M.env_idx[tid] : 0;
+        // (the per-replicate table here, in front of the barrier: the pair descriptors read it)
+        if (S.ldstab) { for (int i = tid; i < 4 * M.R; i += cx.nthr) ((int*)(lds + Y.rtab))[i] = S.ldstab[3 * M.K + 4 * M.Ttot + i]; }
+        else for (int rr = tid; rr < M.R; rr += cx.nthr) br_table_rep(M, Y, rr, (int*)(lds + Y.rtab) + 4 * rr);
+        if (KIND == 2) {
+            int* gx = (int*)(lds + Y.gix);
+            for (int j = tid; j < t.nmt; j += cx.nthr) gx[j] = M.geno_idx[t.m0 + j] - g0;
+            for (int j = tid; j < g1 - g0 && j < Y.SU; j += cx.nthr) {
+                const int g = g0 + j, n = M.geno_ptr[g + 1] - M.geno_ptr[g];
+                gx[Y.SU + j] = (n > 0 ? (int)(M.geno_mem[M.geno_ptr[g]] - t.m0) : 0) | (n << 16);
+            }
+        }
     }
     BB_STAMP_RT(cx, S, 7);          // (thread 0: the segment table is built)
     BB_SYNC(cx);
@@ -514,13 +540,11 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
             for (int i = tid; i < 2 * K; i += cx.nthr) rm[i] = S.ldstab[i];
             for (int i = tid; i < K; i += cx.nthr) ((int*)(lds + L.tmap))[i] = S.ldstab[2 * K + i];
             for (int i = tid; i < 4 * Tt; i += cx.nthr) ((int*)(lds + Y.ftab))[i] = S.ldstab[3 * K + i];
-            for (int i = tid; i < 4 * R; i += cx.nthr) ((int*)(lds + Y.rtab))[i] = S.ldstab[3 * K + 4 * Tt + i];
         }
     } else {
         BB_PASS(cx, tid) {
             for (int j = tid; j < M.K; j += cx.nthr) br_table_row(M, Y, j, rm + 2 * j, (int*)(lds + L.tmap) + j);
             for (int j = tid; j < M.Ttot; j += cx.nthr) br_table_time(M, L, j, (int*)(lds + Y.ftab) + 4 * j);
-            for (int rr = tid; rr < M.R; rr += cx.nthr) br_table_rep(M, Y, rr, (int*)(lds + Y.rtab) + 4 * rr);
         }
     }
     BB_STAMP_RT(cx, S, 9);          // (thread 0's share of the LDS tables)
@@ -540,7 +564,7 @@ BB_DEV void br_prologue(BBCtx& cx, const DevModel& M, const DevState& S, const R
         BRSt<P>& st = BB_PSTATE(stv, tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            br_desc<KIND, P, AP>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, st, k);
+            br_desc<KIND, P, AP>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, st, k, lds);
             const long long i0 = st.i0[k];
             const int meta = st.meta[k];
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;

@@ -89,7 +89,7 @@ BB_DEV void bs_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
         for (int q = 0; q < BR_NCV; ++q) acc.cv[q] = 0.0;
         for (int k = 0; k < P; ++k) {
             BRSt<1> st;
-            br_desc<KIND, 1, false, (TT + 1) / 2, false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, st, 0);
+            br_desc<KIND, 1, false, (TT + 1) / 2, false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, st, 0, lds);
             const int meta = st.meta[0];
             if (!(meta & BRM_VALID)) continue;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
@@ -153,7 +153,7 @@ BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             const int p = tid + k * cx.nthr;
             if (nseg < 1 || sg[0].kind != SK_L || p >= sg[0].tbeg + sg[0].span) break;          // (the loglambda segment comes first: later slots hold unit pairs only)
             BRSt<1> st;
-            br_desc<KIND, 1, false, (TT + 1) / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0);
+            br_desc<KIND, 1, false, (TT + 1) / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0, lds);
             const int meta = st.meta[0];
             if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
             const double* zb = lds + Y.zl + st.zoff[0];
@@ -268,7 +268,7 @@ BB_DEV void bs_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 const int p = tid + k * cx.nthr;
                 if (KIND == 2 && ((p >= th_lo && p < th_hi) != (pass == 1))) continue;      // (the theta segment's pairs: pass 1, everything else: pass 0)
                 BRSt<1> st;
-                br_desc<KIND, 1, false, (TT + 1) / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0);
+                br_desc<KIND, 1, false, (TT + 1) / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
                 const int meta = st.meta[0];
                 if (!(meta & BRM_VALID)) continue;
                 const int kind = meta & 15;

@@ -92,7 +92,7 @@ struct DevState {
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
     const double *segtab;             // k_res / k_stream: the tiles' segment tables, built on the host (bb_engine.hip, host_tables): [tiles][segtab_stride] doubles,
     int segtab_stride;                //   each = (4 + 4 R + 1) BRSeg records + one word with their count; nullptr: thread 0 of a tile builds its own
-    const int *ldstab;                // ... and the tile-independent LDS descriptor tables [rowmap 2 K | tmap K | ftab 4 Ttot | rtab 4 R | envt Ttot]
+    const int *ldstab;                // ... and the tile-independent LDS descriptor tables [rowmap 2 K | tmap K | ftab 4 Ttot | rtab 4 R]
     const long long *tile_b;          // genotype model, k_res: [tiles + 1] first barcode of every tile (cuts fall on genotype boundaries)
     const int *tile_g;                // genotype model, k_res: [tiles + 1] first genotype every tile owns
     unsigned long long *stamps;       // [nblk + 8][32] s_memtime stamps, then [nblk + 8][4][16] per-wave stamps (diagnostic build -DBB_STAMPS only)
