@@ -371,7 +371,9 @@ BB_DEV void br_desc(const DevModel& M, const BRLay& Y, const BBTile& t, const BR
     const int* envt = (const int*)(lds + Y.envt);       // were dependent vector loads from device memory in front of everything else
     const int E = (KIND == 1 || KIND == 4) ? M.E : 1;       // units per (mutant [, replicate]): environments
     int si = -1;
-    for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
+    // (k_stream, a descriptor per slot and pass: most slots sit in the first segment -- the loglambda slab -- and skip the search)
+    if (LPBC && nseg > 0 && p >= sg[0].tbeg && p < sg[0].tbeg + sg[0].span) si = 0;
+    else for (int i = 0; i < nseg; ++i) if (p >= sg[i].tbeg && p < sg[i].tbeg + sg[i].span) si = i;
     int meta = 15;                          // (kind 15: no segment -- SK_L is 0)
     long long i0 = 0;
     st.zoff[k] = 0; st.uo[k][0] = st.uo[k][1] = st.uo[k][2] = 0; st.pt[k] = 0; st.cnt[k][0] = st.cnt[k][1] = 0u;
