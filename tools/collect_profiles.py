@@ -35,7 +35,11 @@ for src, dst in ((f"{tag}_bench.json", "bench.json"), (f"{tag}_bench20.json", "b
     cp(src, dst)
 for c in ("C3", "C4", "C5rank"):
     cp(f"{tag}_validate_{c}.json", f"validate_{c}_3000_iterations.json")
-shutil.copy(os.path.join(G, tag, "hbm_traffic_latest.json"), os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"))
+# (the traffic record names the COMMITTED directory its counter rows sit in, not the scratch tag)
+_t = json.load(open(os.path.join(G, tag, "hbm_traffic_latest.json")))
+_t["source"] = f"profiles/{name} (bash tools/round_end.sh {tag} -> tools/profile_all.sh; pmc_FETCH_SIZE_k_res.csv, pmc_WRITE_SIZE_k_res.csv)"
+json.dump(_t, open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)
+json.dump(_t, open(os.path.join(D, "hbm_traffic.json"), "w"), indent=1)
 for kind in ("kernel_stats", "domain_stats"):
     f = newest(f"{tag}/trace/**/*{kind}.csv")
     if f:
