@@ -116,6 +116,9 @@ def gather_posterior(engine, kind: str, n_neutral: int, n_bc: int, n_time: Seque
     layout: Dict[str, Tuple[int, int]] = {n: (lo, hi) for n, lo, hi in engine.layout()}
     ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env,
                        geno_range=(int(st["geno_lo"]), int(st["geno_hi"])) if kind == "genotype" else None)
+    # shard_lo / shard_hi / geno_lo / geno_hi describe the handle's INTERNAL order (the genotype model's mutants regrouped by
+    # bb_create); posterior() presents the CALLER's order: map the owned entries across (identity when nothing was regrouped)
+    ix = engine.permutation()[ix]
     parts = [None] * dist.get_world_size()
     dist.all_gather_object(parts, (ix, mean[ix], sigma[ix]))
     for i, m, s in parts:

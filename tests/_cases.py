@@ -179,10 +179,11 @@ def case_sharded_split_phase(lib, name, W=3, S=2, nsteps=5):
         for e in es:
             e.step_apply(tot)
     from barbay_jl_amd.sharding import gather_params
+    perms = [e.permutation() for e in es]          # (shard ranges are in the handles' internal order, the vectors in the caller's)
     mu = gather_params([e.get_params()[0] for e in es], [e.stats() for e in es], sp.kind, lay, sp.n_neutral, sp.n_bc,
-                       sp.n_time, sp.n_rep, sp.n_env)
+                       sp.n_time, sp.n_rep, sp.n_env, permutations=perms)
     om = gather_params([e.get_params()[1] for e in es], [e.stats() for e in es], sp.kind, lay, sp.n_neutral, sp.n_bc,
-                       sp.n_time, sp.n_rep, sp.n_env)
+                       sp.n_time, sp.n_rep, sp.n_env, permutations=perms)
     for e in es:
         e.close()
     assert np.abs(mu - m1).max() < 1e-10 and np.abs(om - o1).max() < 1e-10
@@ -382,8 +383,9 @@ def case_p2p_resident(lib, name, world, steps=7):
             for n in (3, steps - 3):                                   # two "launches": inbox words keep counting
                 assert lib.bb_emu_run_group(arr, world, n) == 0, lib.bb_last_error()
             per, st = zip(*[(e.get_params(), e.stats()) for e in es])
+            perms = [e.permutation() for e in es]
             for i, ref in ((0, m1), (1, o1)):
-                full = sharding.gather_params([p[i] for p in per], st, sp.kind, lay, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env)
+                full = sharding.gather_params([p[i] for p in per], st, sp.kind, lay, sp.n_neutral, sp.n_bc, sp.n_time, sp.n_rep, sp.n_env, permutations=perms)
                 assert np.abs(full - ref).max() < 1e-10
         if sp.kind == "genotype":       # theta_g moved on its owner only; the end of the run brought every copy up to date
             tlo, thi = lay["theta"]

@@ -227,6 +227,20 @@ def test_owner_computes_launch_genotype_sharded(emu_lib, monkeypatch, world):
     c.case_multi_device_handle(emu_lib, "genotype_runs", n=world)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_on_scattered_genotypes(emu_lib, monkeypatch, world):
+    """geno_idx in the reference's order of appearance: bb_create regroups the mutants on every rank, the shard ranges then describe
+    the INTERNAL order while get_params presents the caller's -- the gather helpers map ownership through engine.permutation()
+    (without it a rank's owned indices named other ranks' entries)."""
+    monkeypatch.setenv("BB_TUNE_NB", "24")
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    sp = c.synth("genotype", seed=4)
+    from conftest import make_engine
+    with make_engine(sp, emu_lib, rank=0, world_size=world) as e:
+        assert not (e.permutation() == np.arange(e.D)).all()
+    c.case_p2p_resident(emu_lib, "genotype", world)
+
+
 def test_genotype_empty_genotypes_and_unsorted(emu_lib, monkeypatch):
     """genotypes without mutants (theta_g feels its prior only) ride with the tile before them; geno_idx that is not in
     consecutive runs keeps the two-kernel step"""
