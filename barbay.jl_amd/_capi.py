@@ -25,7 +25,7 @@ BB_ERR_NONFINITE = -5
 EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
     "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_get_permutation", "bb_run", "bb_run_profiled",
-    "bb_get_posterior", "bb_elbo_grad", "bb_logdensity_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats",
+    "bb_get_posterior", "bb_elbo_grad", "bb_logdensity_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats", "bb_kernel_name",
     "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply", "bb_hier_units", "bb_hier_fitness", "bb_p2p_export", "bb_p2p_import", "bb_p2p_selftest", "bb_p2p_enable",
 ]
 
@@ -108,6 +108,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.bb_get_elbo_trace.argtypes = [vp, C.c_int64, C.c_int64, _dp]
     lib.bb_debug_normals.argtypes = [vp, C.c_int64, C.c_uint32, C.c_int64, C.c_int64, _dp]
     lib.bb_get_stats.argtypes = [vp, C.POINTER(bb_stats)]
+    if hasattr(lib, "bb_kernel_name"):          # (A/B builds of older sources, tools/xp.py)
+        lib.bb_kernel_name.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.bb_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     lib.bb_comm_make_id.argtypes = [C.c_void_p]
     lib.bb_comm_init.argtypes = [vp, C.c_void_p]
@@ -330,6 +332,12 @@ class Engine:
         s = bb_stats()
         self._check(self._lib.bb_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in bb_stats._fields_}
+
+    def kernel_name(self) -> str:
+        """The kernel `run` launches, as text: the template instance, e.g. 'k_res<0,1,1024,false,8,false,false>' (`bb_kernel_name`)."""
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.bb_kernel_name(self._h, buf, 128))
+        return buf.value.decode()
 
     def logdensity_grad(self, z) -> Tuple[float, np.ndarray]:
         """log p(data, z) and its gradient at a point of the flat latent vector (`bb_logdensity_grad`)."""

@@ -438,12 +438,13 @@ static int launch_check();
 // persistent launch (bb_persist.h)
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_EMU
-static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false) {
+static bb_persist_kernel persist_kernel(int kind, int P, int nthr, bool xg = false, const char** nm = nullptr) {
 #ifdef BB_FAST_BUILD   /* experiment builds (tools/xp.py): only the instances the C2 / C4 workloads use, in this one translation unit */
+    if (nm) *nm = "(experiment build)";
     if (!xg && nthr > 512 && P == 1 && kind == 0) return k_persist<0, 1, 1024>;
     return nullptr;
 #else
-    return bb_persist_instance(kind, P, nthr, xg);
+    return bb_persist_instance(kind, P, nthr, xg, nm);
 #endif
 }
 #endif
@@ -455,8 +456,9 @@ static int uniform_T(const DevModel& M) {
 }
 
 #ifndef BB_EMU
-static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool ap, bool ms = false) {
+static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool ap, bool ms = false, const char** nm = nullptr) {
 #ifdef BB_FAST_BUILD
+    if (nm) *nm = "(experiment build)";
     if (xg || ms) return nullptr;
     if (ap) {
         if (nthr > 512 && P == 1 && kind == 0) return k_res<0, 1, 1024, false, 0, true>;
@@ -473,24 +475,25 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool 
 #else
     if (ms && xg) return nullptr;              // (several samples per step / ELBO recording: single-GPU instances only)
     switch (kind) {
-    case 0: return bb_res_instance_k0(P, nthr, xg, T, ap, ms);
-    case 1: return bb_res_instance_k1(P, nthr, xg, T, ap, ms);
-    case 2: return bb_res_instance_k2(P, nthr, xg, T, ap, ms);
-    case 3: return bb_res_instance_k3(P, nthr, xg, T, ap, ms);
-    default: return bb_res_instance_k4(P, nthr, xg, T, ap, ms);
+    case 0: return bb_res_instance_k0(P, nthr, xg, T, ap, ms, nm);
+    case 1: return bb_res_instance_k1(P, nthr, xg, T, ap, ms, nm);
+    case 2: return bb_res_instance_k2(P, nthr, xg, T, ap, ms, nm);
+    case 3: return bb_res_instance_k3(P, nthr, xg, T, ap, ms, nm);
+    default: return bb_res_instance_k4(P, nthr, xg, T, ap, ms, nm);
     }
 #endif
 }
 #endif
 
 #ifndef BB_EMU
-static bb_stream_kernel stream_kernel(int kind, int nthr, int T) {
+static bb_stream_kernel stream_kernel(int kind, int nthr, int T, const char** nm = nullptr) {
 #ifdef BB_FAST_BUILD
+    if (nm) *nm = "(experiment build)";
     if (nthr == 1024 && kind == 0 && T == 8) return k_stream<0, 1024, 8>;
     if (nthr == 1024 && kind == 2 && T == 8) return k_stream<2, 1024, 8>;
     return nullptr;
 #else
-    return bb_stream_instance(kind, nthr, T);
+    return bb_stream_instance(kind, nthr, T, nm);
 #endif
 }
 #endif
@@ -612,6 +615,10 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     // GPU runs 512 of them); a resident launch needs every tile resident -- one per compute unit: its own base map then
     int NB0 = h->NB, nblk0 = h->nblk;
     if (nblk0 > h->cus && !getenv("BB_TUNE_NB")) { NB0 = (int)((nbar + h->cus - 1) / h->cus); nblk0 = (int)((nbar + NB0 - 1) / NB0); }
+    // BB_TUNE_RES_NB (tests): the resident launch's own tile size -- a cut of a BASELINE problem with the full-size tile geometry even where
+    // the two-kernel step's tables would not fit such a tile (config 5 on one GPU: 782 barcodes per tile)
+    const char* res_nb = getenv("BB_TUNE_RES_NB");
+    if (res_nb && atoi(res_nb) > 0) { NB0 = atoi(res_nb); nblk0 = (int)((nbar + NB0 - 1) / NB0); }
     int NB = NB0, NBL = 0, nblk = nblk0;
     // Groups of the exchange's first hop.  Round 2: 16 on one GPU (a leader then fetched its 16 members' rows in one round of loads, the
     // consume ran on two thread groups).  Round 3, tagged rows + leaders that poll their members in chunks of eight on as many thread
@@ -634,7 +641,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     const int NGh = h->res_ng;
     int pct = (ev = getenv("BB_TUNE_LEAD")) ? atoi(ev) : 65;
     if (pct < 10 || pct > 100) pct = 100;
-    const bool nb_fixed = getenv("BB_TUNE_NB") != nullptr;
+    const bool nb_fixed = getenv("BB_TUNE_NB") != nullptr || (res_nb && atoi(res_nb) > 0);
     ev = getenv("BB_TUNE_LEAD");
     if (pct < 100 && nblk0 >= 2 * NGh && (!nb_fixed || ev)) {
         if (!nb_fixed) {
@@ -886,27 +893,28 @@ template <int KIND, int TT>
 static void emu_stream_phase(EmuPersist& E, int phase, long long it, long long nsteps) {
     bb_handle* h = E.h;
     const RunArgs& A = E.A;
-    BSAcc* acc = (BSAcc*)E.st.data();
+    BSG* gs = (BSG*)E.st.data();
     auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), nullptr}; };
     const BRLay& Y = h->Yh;
     const unsigned long long step = (unsigned long long)(h->step + it);
     BRSt<1>* nost = nullptr;
     for (int b = 0; b < (phase == 2 ? bbp_groups(A) : h->res_nblk); ++b) {
         BBCtx cx = cxof(b);
-        BSAcc* ab = acc + (size_t)b * h->nthr;
+        BSG* gb = gs + (size_t)b * h->nthr;
         int* bad_any = (int*)(cx.lds + Y.L.misc) + 3;
         if (phase == 0) {
             br_tile_setup<KIND>(cx, h->M, h->S, A, Y, h->res_NB, h->nthr / 16);
             *bad_any = 0;
+            bs_sample0<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)h->step, gb);      // (the launch's first sample; later ones: inside the G passes)
         } else if (phase == 1) {
-            bs_sample<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, ab);
-            bs_moments<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, ab);
+            bs_moments<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, gb);
             br_row_publish<1, true, false>(cx, h->M, h->S, Y, nost, A.xepoch0 + (unsigned)(step + 1));
         } else if (phase == 2) {
             br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
         } else if (phase == 3) {
             br_xchg_consume<KIND, 1, false, false>(cx, h->M, h->S, A, Y, nost, step, &E.ok);
-            bs_update<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any);
+            bs_update_l<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any, gb);
+            bs_update_u<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any, gb);
         } else {
             if (*bad_any) h->S.hstatus[1] = 1u;
             if (b == 0) { h->S.ctr[0] = (unsigned long long)(h->step + nsteps); h->S.ctr[1] = h->S.ctr[0]; }
@@ -976,7 +984,7 @@ static int emu_run_group(bb_handle** hs, int n, long long nsteps) {
         es[i].A = make_args(h, h->step, 0, h->res_P ? h->o.samples_per_step : 1, true, false);
         if (h->res_P) { es[i].A.nblk = h->res_nblk; es[i].A.nbl = h->res_NBL; es[i].A.ng = h->res_ng; es[i].A.pf = h->res_pf; }
         es[i].lds.assign((size_t)std::max(h->nblk, h->res_nblk) * (h->lds_doubles_p + 64), 0.0);
-        es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_stream ? sizeof(BSAcc) : (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P))), 0);
+        es[i].st.assign((size_t)std::max(h->nblk, h->res_nblk) * h->nthr * (h->res_stream ? sizeof(BSG) : (h->res_P ? emu_rst_bytes(h->res_P) : emu_pst_bytes(h->persist_P))), 0);
         emu_persist_dispatch(es[i], 0, 0, nsteps);
     }
     const long long NS = hs[0]->res_P ? std::max(hs[0]->o.samples_per_step, 1) : 1;
@@ -1554,11 +1562,14 @@ static int launch_check() {
 // two-kernel launchers calls this first (never from inside a stream capture); the resident launches use none of them.
 static int ensure_scratch(bb_handle* h) {
     if (h->S.zsv) return BB_OK;
-    const size_t D = (size_t)h->M.D;
-    int rc;
-    if ((rc = dalloc(h, &h->S.zsv, D + 2)) || (rc = dalloc(h, &h->S.asv, D + 2)) || (rc = dalloc(h, &h->S.hsv, D + 2)) ||
-        (rc = dalloc(h, &h->S.gacc_mu, D + 2)) || (rc = dalloc(h, &h->S.gacc_om, D + 2)) ||
-        (rc = dalloc(h, &h->bak_mu, D + 2)) || (rc = dalloc(h, &h->bak_om, D + 2))) { h->S.zsv = nullptr; return rc; }
+    // ONE slab carved into the seven arrays: a failed allocation leaves nothing behind (seven separate ones left the earlier arrays
+    // in h->owned with stale pointers in S, and a retry allocated them all again -- ADVICE r03)
+    const size_t D = (size_t)h->M.D, n = (D + 2 + 1) & ~(size_t)1;
+    double* slab = nullptr;
+    int rc = dalloc(h, &slab, 7 * n);
+    if (rc) return rc;
+    h->S.zsv = slab; h->S.asv = slab + n; h->S.hsv = slab + 2 * n; h->S.gacc_mu = slab + 3 * n; h->S.gacc_om = slab + 4 * n;
+    h->bak_mu = slab + 5 * n; h->bak_om = slab + 6 * n;
     return h->dS ? h2d(h->dS, &h->S, sizeof(DevState), h->stream) : BB_OK;      // (kernels read the descriptor through its device copy)
 }
 
@@ -2607,6 +2618,32 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->persistent_pairs = h->persist_P;
     s->launches_last_run = h->launches_last_run;
     s->resident_kernel = h->res_P > 0 ? (h->res_stream ? 3 : 2) : (h->persist_P > 0 ? 1 : 0);
+    return BB_OK;
+}
+
+// The kernel bb_run launches, as text: the template instance in declaration order -- k_res<KIND, P, NT, XG, TT, AP, MS>,
+// k_stream<KIND, NT, TT>, k_persist<KIND, P, NT[, XG]> -- or "k_sample + k_update" for the two-kernel step.  Tests and bench.py
+// print / assert THIS instead of reconstructing the instance from bb_stats.
+extern "C" int bb_kernel_name(bb_handle* h, char* buf, int64_t len) {
+    if (!h || !buf || len < 2) return bb_fail(BB_ERR_INVALID, "null argument / no room");
+    if (!h->shards.empty()) return bb_kernel_name(h->shards[0], buf, len);
+    const char* nm = "";
+    char tmp[96];
+#ifdef BB_EMU
+    // (the emulation runs the block programs as host functions: it names the launch, the compile-time T / AP / MS are the product's)
+    if (h->res_P && h->res_stream) snprintf(tmp, sizeof tmp, "emu:k_stream<%d,%d,%d>", h->M.kind, h->nthr, uniform_T(h->M));
+    else if (h->res_P) snprintf(tmp, sizeof tmp, "emu:k_res<%d,%d,%d,%s,*,%s,%s>", h->M.kind, h->res_P, h->nthr, h->p2p_on ? "true" : "false",
+                                br_any_parity(h->M) ? "true" : "false", (h->o.samples_per_step != 1 || h->o.elbo_every != 0) ? "true" : "false");
+    else if (h->persist_P) snprintf(tmp, sizeof tmp, "emu:k_persist<%d,%d,%d>", h->M.kind, h->persist_P, h->nthr);
+    else snprintf(tmp, sizeof tmp, "emu:k_sample + k_update");
+    nm = tmp;
+#else
+    if (h->res_P && h->res_stream) (void)stream_kernel(h->M.kind, h->nthr, uniform_T(h->M), &nm);
+    else if (h->res_P) (void)res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), res_ms(h), &nm);
+    else if (h->persist_P) (void)persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on, &nm);
+    else { snprintf(tmp, sizeof tmp, "k_sample<%d> + k_update<%d>", h->M.kind, h->M.kind); nm = tmp; }
+#endif
+    snprintf(buf, (size_t)len, "%s", nm);
     return BB_OK;
 }
 

@@ -1,7 +1,8 @@
 // bb_inst_stream.hip -- the k_stream instances (bb_stream.h), one translation unit of the library (see bb_inst.h)
 #include "bb_inst.h"
-bb_stream_kernel bb_stream_instance(int kind, int nthr, int T) {
-#define BS_CASE(K, NT, TT) if (kind == (K) && nthr == (NT) && T == (TT)) return k_stream<K, NT, TT>;
+bb_stream_kernel bb_stream_instance(int kind, int nthr, int T, const char** nm) {
+    if (nm) *nm = "";
+#define BS_CASE(K, NT, TT) if (kind == (K) && nthr == (NT) && T == (TT)) { if (nm) *nm = "k_stream<" #K "," #NT "," #TT ">"; return k_stream<K, NT, TT>; }
     BS_CASE(0, 1024, 8) BS_CASE(1, 1024, 8) BS_CASE(2, 1024, 8)
     BS_CASE(0, 1024, 4) BS_CASE(1, 1024, 4) BS_CASE(2, 1024, 4)
     BS_CASE(0, 512, 8) BS_CASE(1, 512, 8) BS_CASE(2, 512, 8)

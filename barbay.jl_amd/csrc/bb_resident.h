@@ -129,11 +129,13 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     Y.NBT = 0;
     for (int r = 0; r < BB_MAX_REP; ++r) { Y.zr0[r] = Y.NBT; if (r < M.R) Y.NBT += NB * (M.T[r] + 1); }
     Y.NBT = (Y.NBT + 1) & ~1;
-    Y.zlw = stream ? 1 : 2;          // (k_stream, bb_stream.h: single buffers -- a barrier ends its step)
+    // (k_stream, bb_stream.h: no z rows at all -- the region holds a loglambda pair's two forward differences, one private 16-byte entry per
+    //  pair, [NB][T] doubles at most; its unit stage tables are double-buffered like k_res's, but only the forms OTHER threads read are staged)
+    Y.zlw = stream ? 1 : 2;
     Y.zl = o;      o += Y.zlw * Y.NBT;
     Y.SU = NB * X;
-    Y.nst = M.kind <= 1 ? 3 : 6;
-    Y.stw = Y.zlw * Y.SU;
+    Y.nst = stream ? (M.kind <= 1 ? 2 : 4) : (M.kind <= 1 ? 3 : 6);
+    Y.stw = 2 * Y.SU;
     for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += Y.stw; }
     o = (o + 1) & ~1;
     Y.rowmap = o;  o += M.K + 1;          // [K] int pairs
@@ -181,9 +183,11 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     const int xg_want = (!BR_TG && xg_rows > 0) ? (xg_rows * KK < (BB_NQ + 1) * NT ? xg_rows * KK : (BB_NQ + 1) * NT) : 0;
     int busy;           // doubles of the transient region alive during the exchange
     if (stream) {
-        Y.hbuf = Y.eps = Y.racc;         // (neither exists: normals and window slots go through registers)
-        busy = racc_total;
-        o += racc_total;
+        // (no normals, no window slot in LDS: they go through registers.  hbuf = the units' sums (As, Qs) [SU] pairs, written by the loglambda
+        //  lanes in the G pass -- the contributions are dead by then -- and read by the unit threads)
+        Y.hbuf = Y.eps = Y.racc;
+        busy = racc_total > 2 * Y.SU ? racc_total : 2 * Y.SU;
+        o += busy;
     } else if (own_hbuf) {
         // the window slot is fetched while the moment contributions are alive (RunArgs.pf = 1, 2): a region of its own
         Y.eps = Y.racc;

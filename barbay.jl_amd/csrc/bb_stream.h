@@ -6,20 +6,35 @@
 // two kernels per step -- 184 B per latent of traffic, six launches per step, 135.8 us (0.20 of the HBM roofline).
 //
 // k_stream keeps k_res's tile map, segment table, moment algebra and in-launch exchange, and STREAMS the per-pair state: a thread
-// walks its P pair slots (p = tid + k NT) twice per step,
-//   S   mu, omega in (16 B per latent), Philox draw, softplus / sigmoid, z = mu + sigma eps, lambda = e^z; z and the unit forms staged
-//       in LDS (single-buffered: a barrier ends the step), the lambdas summed per thread
-//   --  barrier 1
-//   M   the loglambda pairs' differences and moment contributions (neighbours and unit forms from LDS), summed per thread over its
-//       slots -- a thread's pairs share their time-pair class (NT is a multiple of the lanes per barcode) -- then by class over the
-//       16-lane rows of the wave (DPP), one LDS entry per (row, class, value)
-//   --  barrier 2 -- row sums, publish, exchange, F pass: k_res's own code (br_row_publish, bbp_*_tg, br_finish)
-//   G   per slot: mu, omega, accumulators, window slot in (60 B per latent), the draw AGAIN (Philox is a pure function of (seed, latent,
-//       step): recomputing it and the softplus costs ~300 VALU instructions per pair, keeping eps sigmoid and sigmoid / softplus in
-//       memory across the exchange would cost 32 B per latent -- the launch is bandwidth-bound, the VALUs are not), lambda = e^z from the
-//       staged z, gradient, optimiser, everything out (56 B per latent)
-// = 132 B per latent and step against 112 algorithmic (96 + the accumulators' low-order floats) -- the S pass's second read of mu,
-// omega is the difference, and hits the Infinity Cache.
+// walks its P pair slots (p = tid + k NT) ONCE per step (round 4; round 3 walked them twice -- an S pass that read mu, omega and
+// sampled, then, after the exchange, a G pass that read everything again: 80.6 us per step on C5, the memory system idle for the
+// 37 % of it that S, M and the exchange took).  A step:
+//
+//   M    the loglambda pairs' moment contributions from what the previous step's G pass left in LDS -- per pair the two forward
+//        differences (dm, dn) of ITS sample (thread-private entries, no barrier needed for them) and the units' staged forms
+//        (s, w = e^{-2 logsigma}, e^{logtau}, theta) -- summed per thread over its slots (a thread's pairs share their time-pair
+//        class: NT is a multiple of the lanes per barcode), then by class over the 16-lane rows of the wave (DPP), one LDS entry
+//        per (row, class, value)
+//   --   barrier -- row sums, publish, exchange, F pass: k_res's own code (br_row_publish, bbp_*_tg, br_finish)
+//   G-L  every loglambda pair slot, ONE pass over its state: mu, omega, accumulators, window slot in (56 B per latent); the step's
+//        draw AGAIN (Philox is a pure function of (seed, latent, step): nothing of the sample was kept but the differences), z = mu +
+//        sigma eps, the neighbour pairs' z through DPP (the lanes of a barcode are neighbours in a 16-lane row), lambda = e^z,
+//        gradient, optimiser, everything out (56 B per latent).  The lanes of a barcode add their residuals r, r^2 up (DPP) and
+//        leave the barcode's unit sums As = sum_t r, Qs = sum_t r^2 in LDS -- the unit threads no longer walk z rows, so no z row
+//        is staged at all.  THEN, in the same slot, the NEXT step's sample of the updated pair: draw, z' = mu' + sigma' eps', the
+//        neighbour's z' by DPP, (dm', dn') to the thread's private LDS entry, lambda' = e^{z'} onto the thread's running sums.
+//   --   barrier (As, Qs visible)
+//   G-U  the unit pair slots the same way: state in, the draw again, gradient from (As, Qs) and the staged forms of THIS step
+//        (buffer step & 1), optimiser, out; then the next step's sample, staged into buffer (step + 1) & 1.  Genotype model: theta
+//        after one more barrier (its gradient sums the w As its mutants' theta_tilde threads left in LDS).
+//   --   barrier: the step's tables are complete
+//
+// The S pass's arithmetic now runs inside the pass that is bound by memory, its second read of mu, omega (16 B per latent) is gone,
+// and nothing but M, the exchange and F runs with the memory system idle: 112 B per latent and step + the counts (4 B per loglambda
+// latent) against 96 + 16 (the accumulators' low-order floats) algorithmic.  LDS: the z rows ([NB][T + 1] doubles, 56 KB on C5)
+// became the private differences ([NB][T]); the unit stage tables are double-buffered by step parity but only the forms somebody
+// ELSE reads are staged (an owner recomputes its own sample with its draw): fitness / multienv 2 tables (s, w), hierarchical 4
+// (theta_tilde, e^logtau, w, theta) -- C5's tile: 141 -> 154 KB.  The launch starts with the first step's sample alone (bs_sample0).
 //
 // Shapes: one replicate (fitness, multienv, genotype kinds), an even number of time points whose lanes per barcode divide 16
 // (T = 2, 4, 8, 16; instances for the BASELINE shapes' T = 8 and for 4), flat-index-aligned pairs (no AP), one GPU, one MC sample per
@@ -27,9 +42,22 @@
 #pragma once
 #include "bb_resident.h"
 
-struct BSAcc { double cv[BR_NCV]; };      // a thread's moment contributions, summed over its pair slots
+// per-thread state of the passes (GPU: registers of the one thread; emulation: an array over the tile's threads, so that the lanes'
+// DPP exchanges can be written as "pass A leaves a value, pass B reads the neighbour's")
+struct BSG {
+    BRSt<1> st;                       // the slot's pair descriptor (br_desc)
+    bb_d2 mu, om, am, ao, hm, ho;     // state of the pair and its window slot
+    bb_f4 lo;
+    bb_d2 e, z, sg, sp;               // the step's draw, sample, sigmoid / softplus of omega
+    double g0, g1, zv0, zv1;          // likelihood gradient and sample of the two latents
+    double rm, rn;                    // loglambda, mutant: residuals of the pair's two forward differences
+    double xa, xq;                    // ... and what of them goes to the unit sums being formed (one environment at a time)
+    double lam0, lam1;                // running sums of lambda over the thread's loglambda slots: the NEXT step's S_t contributions
+    double cv[BR_NCV];                // M pass: the thread's moment contributions
+    int ok;                           // slot holds a pair of the kind the pass handles
+};
 
-// the step's normals of pair i0 (flat-index-aligned): out of line, as br_draw_call, so that its temporaries stay out of the slot loops
+// the step's normals of pair i0 (flat-index-aligned): out of line (as br_draw_call) where its temporaries would crowd a slot loop
 #ifdef BB_EMU
 static inline
 #else
@@ -40,27 +68,26 @@ bb_d2 bs_draw(unsigned long long seed, long long i0, unsigned step) {
     bb_normal_pair(seed, (unsigned long long)(i0 >> 1), step, 0u, &a, &b);
     return bb_d2{a, b};
 }
-
 BB_DEV bb_d2 bs_draw_inline(unsigned long long seed, long long i0, unsigned step) {
     double a, b;
     bb_normal_pair(seed, (unsigned long long)(i0 >> 1), step, 0u, &a, &b);
     return bb_d2{a, b};
 }
-// (inline in the G pass: the pair's state loads stay in flight behind it -- a call drains them first; C5 93.1 -> 91.4 us)
+// (inline in the G pass: the pair's state loads stay in flight behind it -- a call drains them first; C5 93.1 -> 91.4 us, round 3)
 #ifndef BS_G_INLINE_DRAW
 #define BS_G_INLINE_DRAW 1
 #endif
-// BS_KEEP_AH = 1: eps sigmoid and sigmoid / softplus go through memory (S.asv, S.hsv) from the S pass to the G pass instead of being
-// recomputed there (+32 B per latent of traffic, -330 VALU instructions per pair): measured SLOWER, C5 90.8 -> 108.2 us -- the G pass is
-// bandwidth-bound (profiles/r03d_stream_c5)
-#ifndef BS_KEEP_AH
-#define BS_KEEP_AH 0
+// ... and the NEXT step's draw inside the same slot (the fused S part): 1 = inline, 0 = the out-of-line call
+#ifndef BS_S_INLINE_DRAW
+#define BS_S_INLINE_DRAW 0
 #endif
 // BS_NT_HIST = 1: the window slot is read with the non-temporal policy (it is not touched again for a whole window; the state arrays,
-// re-read every step, keep the Infinity Cache): C5 90.8 -> 83.9 us
+// re-read every step, keep the Infinity Cache): C5 90.8 -> 83.9 us (round 3)
 #ifndef BS_NT_HIST
 #define BS_NT_HIST 1
 #endif
+
+// ---- lane exchanges: value of the previous / next lane of the 16-lane row, sum over the LPB lanes of a barcode ------------------------
 #ifndef BB_EMU
 template <int CTRL> __device__ __forceinline__ double bs_dpp_add(double x) { return x + br_dpp<CTRL>(x); }
 // sum over the lanes of a 16-lane row with equal (lane % LPB): rotations by 8, 4, .. down to LPB
@@ -71,107 +98,154 @@ template <int LPB> __device__ __forceinline__ double bs_class_sum(double x) {
     if (LPB <= 1) x = bs_dpp_add<0x121>(x);
     return x;
 }
+// sum over the LPB consecutive lanes of a barcode (aligned groups of LPB lanes; every lane gets it): quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror -- a pairwise tree, ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7))
+template <int LPB> __device__ __forceinline__ double bs_group_sum(double x) {
+    if (LPB >= 2) x = bs_dpp_add<0xB1>(x);
+    if (LPB >= 4) x = bs_dpp_add<0x4E>(x);
+    if (LPB >= 8) x = bs_dpp_add<0x141>(x);
+    return x;
+}
+#define BS_PREV(gv, tid, F) br_dpp<0x111>(BB_PSTATE(gv, tid).F)       /* row_shr:1 -- lane i gets lane i - 1's (first lane of a row: 0) */
+#define BS_NEXT(gv, tid, F) br_dpp<0x101>(BB_PSTATE(gv, tid).F)       /* row_shl:1 -- lane i gets lane i + 1's (last lane of a row: 0)  */
+#define BS_GROUP_SUM(LPB, gv, tid, F) bs_group_sum<LPB>(BB_PSTATE(gv, tid).F)
+#else
+#define BS_PREV(gv, tid, F) (((tid) & 15) ? (gv)[(tid) - 1].F : 0.0)
+#define BS_NEXT(gv, tid, F) ((((tid) & 15) != 15) ? (gv)[(tid) + 1].F : 0.0)
+template <int LPB> static inline double bs_emu_tree(const double* v) {          // the GPU's pairwise tree, same order
+    if (LPB == 1) return v[0];
+    double t[8];
+    int n = LPB;
+    for (int i = 0; i < n; ++i) t[i] = v[i];
+    while (n > 1) { for (int i = 0; i < n / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1]; n /= 2; }
+    return t[0];
+}
+#define BS_GROUP_SUM(LPB, gv, tid, F) ([&]() { double v_[8]; for (int i_ = 0; i_ < (LPB); ++i_) v_[i_] = (gv)[((tid) & ~((LPB) - 1)) + i_].F; return bs_emu_tree<LPB>(v_); }())
 #endif
 
-// ---- S: every pair slot -- state in, draw, sample, stage ---------------------------------------------------------------------
+// number of pair slots that hold loglambda pairs (the loglambda segment comes first, at thread index 0), and its span
+BB_DEV int bs_lspan(const BRSeg* sg, int nseg) { return (nseg > 0 && sg[0].kind == SK_L) ? sg[0].tbeg + sg[0].span : 0; }
+
+// ---- the sample of a pair: z = mu + softplus(omega) eps ------------------------------------------------------------------------------
+BB_DEV bb_d2 bs_z(const bb_d2 mu, const bb_d2 om, const bb_d2 e, bb_d2* sp, bb_d2* sg) {
+    double sp0, sg0, sp1, sg1;
+    bb_softplus_sigmoid(om.x, &sp0, &sg0);
+    bb_softplus_sigmoid(om.y, &sp1, &sg1);
+    *sp = bb_d2{sp0, sp1};
+    *sg = bb_d2{sg0, sg1};
+    return bb_d2{fma(sp0, e.x, mu.x), fma(sp1, e.y, mu.y)};
+}
+// what a loglambda pair leaves for the NEXT step's M pass: its two forward differences in the thread's private LDS entry, lambda on the
+// thread's running sums (zn: the next pair's first sample, by DPP)
+BB_DEV void bs_put_l(double* lds, const BRLay& Y, int q, int meta, const bb_d2 z, double zn, BSG& g) {
+    if (!(meta & BRM_VALID)) return;
+    const bool hn = meta & BRM_NEXT;
+    *(bb_d2*)(lds + Y.zl + 2 * q) = bb_d2{z.y - z.x, hn ? zn - z.y : 0.0};
+    g.lam0 += bb_exp(z.x);
+    g.lam1 += bb_exp(z.y);
+}
+// ... and a unit pair: the forms OTHER threads read, into the stage tables of buffer `buf` (an owner recomputes its own sample)
+template <int KIND>
+BB_DEV void bs_put_u(double* lds, const DevModel& M, const BRLay& Y, const RunArgs& A, const BRSt<1>& st, int buf, const bb_d2 z) {
+    const BBLds& L = Y.L;
+    const int meta = st.meta[0], kind = meta & 15;
+    const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+    if (!(meta & BRM_VALID)) return;
+    if (kind < SK_GS) {
+        const int raw = br_stage_raw<KIND>(kind), trn = br_stage_trn<KIND>(kind);
+        if (raw < Y.nst) {
+            double* dst = lds + BR_ST(Y, raw) + buf * Y.SU + st.zoff[0];
+            if (a0) dst[0] = z.x;
+            if (a1) dst[1] = z.y;
+        }
+        if (trn >= 0) {
+            const double f = (kind == SK_LS_E || (KIND >= 2 && kind == SK_LS_R)) ? -2.0 : 1.0;      // logsigma: precision w = e^{-2 z}; logtau: e^{logtau}
+            double* dw = lds + BR_ST(Y, trn) + buf * Y.SU + st.zoff[0];
+            if (a0) dw[0] = bb_exp(f * z.x);
+            if (a1) dw[1] = bb_exp(f * z.y);
+        }
+    } else if (A.count_globals) {      // replicated global latents (tile 0 only): they ride along in the tile's row
+        double* dst = lds + L.wk + M.K + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
+        if (a0) dst[0] = z.x;
+        if (a1) dst[1] = z.y;
+    }
+}
+
+// ---- the launch's first sample (every later one is formed inside the G passes of the step before it) -------------------------------
 template <int KIND, int TT>
-BB_DEV void bs_sample(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSAcc* accv) {
+BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
     const int g0 = KIND == 2 ? S.tile_g[cx.block] : 0, g1 = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
+    const int lspan = bs_lspan(sg, nseg);
     BB_STAMP(cx, S, 20);
-    BB_PASS(cx, tid) {
-        BSAcc& acc = BB_PSTATE(accv, tid);
-#pragma unroll
-        for (int q = 0; q < BR_NCV; ++q) acc.cv[q] = 0.0;
-        for (int k = 0; k < P; ++k) {
-            BRSt<1> st;
-            br_desc<KIND, 1, false, (TT + 1) / 2, false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, st, 0, lds);
-            const int meta = st.meta[0];
-            if (!(meta & BRM_VALID)) continue;
-            const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-            const int kind = meta & 15;
-            const bb_d2 mu = br_load_pair<false>(S.mu, st.i0[0], a0, a1), om = br_load_pair<false>(S.om, st.i0[0], a0, a1);
-            const bb_d2 e = bs_draw(A.seed, st.i0[0], step);
-            double sp0, sg0, sp1, sg1;
-            bb_softplus_sigmoid(om.x, &sp0, &sg0);
-            bb_softplus_sigmoid(om.y, &sp1, &sg1);
-            const double z0 = fma(sp0, e.x, mu.x), z1 = fma(sp1, e.y, mu.y);
-            if (BS_KEEP_AH) {
-                br_store_pair<false>(S.asv, st.i0[0], a0, a1, bb_d2{e.x * sg0, e.y * sg1});
-                br_store_pair<false>(S.hsv, st.i0[0], a0, a1, bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)});
-            }
-            const double f = (kind == SK_LS_E || (KIND >= 2 && kind == SK_LS_R)) ? -2.0 : 1.0;      // logsigma: precision w = e^{-2 z}; logtau: e^{logtau}
-            const bool need_exp = kind == SK_L || br_stage_trn<KIND>(kind) >= 0;
-            const double l0 = need_exp ? bb_exp(f * z0) : 0.0, l1 = need_exp ? bb_exp(f * z1) : 0.0;
-            if (kind == SK_L) {
-                double* zw = lds + Y.zl + st.zoff[0];
-                zw[0] = z0;
-                zw[1] = z1;
-                acc.cv[0] += l0;
-                acc.cv[6] += l1;
-            } else if (kind < SK_GS) {
-                const int raw = br_stage_raw<KIND>(kind), trn = br_stage_trn<KIND>(kind);
-                double* dst = lds + BR_ST(Y, raw) + st.zoff[0];
-                if (a0) dst[0] = z0;
-                if (a1) dst[1] = z1;
-                if (trn >= 0) {
-                    double* dw = lds + BR_ST(Y, trn) + st.zoff[0];
-                    if (a0) dw[0] = l0;
-                    if (a1) dw[1] = l1;
-                }
-            } else {      // replicated global latents (tile 0 only): they ride along in the tile's row
-                double* dst = lds + L.wk + M.K + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
-                if (A.count_globals) {
-                    if (a0) dst[0] = z0;
-                    if (a1) dst[1] = z1;
-                }
+    BB_PASS(cx, tid) { BSG& g = BB_PSTATE(gv, tid); g.lam0 = g.lam1 = 0.0; }
+    for (int k = 0; k < P; ++k) {
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+            br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, g.st, 0, lds);
+            const int meta = g.st.meta[0];
+            g.z = bb_d2{0.0, 0.0};
+            if (meta & BRM_VALID) {
+                const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+                const bb_d2 mu = br_load_pair<false>(S.mu, g.st.i0[0], a0, a1), om = br_load_pair<false>(S.om, g.st.i0[0], a0, a1);
+                g.z = bs_z(mu, om, bs_draw(A.seed, g.st.i0[0], step), &g.sp, &g.sg);
             }
         }
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+            const double zn = BS_NEXT(gv, tid, z.x);
+            const int p = tid + k * cx.nthr, meta = g.st.meta[0];
+            if (p < lspan) bs_put_l(lds, Y, p - sg[0].tbeg, meta, g.z, zn, g);
+            else bs_put_u<KIND>(lds, M, Y, A, g.st, (int)(step & 1u), g.z);
+        }
     }
-    BB_SYNC(cx);                     // barrier 1: every z and unit form of the tile is staged
+    BB_SYNC(cx);
     BB_STAMP(cx, S, 21);
 }
 
 // ---- M: the loglambda pairs' moment contributions, summed per thread, then by class over the wave's rows, one LDS entry each ----
 template <int KIND, int TT>
-BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, BSAcc* accv) {
+BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
     const int g0 = KIND == 2 ? S.tile_g[cx.block] : 0, g1 = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
-    constexpr int LPB = (TT + 1) / 2;
-    const int stride = Y.rw[0] + 4;
+    constexpr int LPB = TT / 2;
+    const int stride = Y.rw[0] + 4, buf = (int)(step & 1u), lspan = bs_lspan(sg, nseg);
+    BB_STAMP(cx, S, 22);
     BB_PASS(cx, tid) {
-        BSAcc& acc = BB_PSTATE(accv, tid);
+        BSG& g = BB_PSTATE(gv, tid);
+#pragma unroll
+        for (int q = 0; q < BR_NCV; ++q) g.cv[q] = 0.0;
+        g.cv[0] = g.lam0; g.cv[6] = g.lam1;          // (summed while the pairs were sampled)
+        g.lam0 = g.lam1 = 0.0;
         for (int k = 0; k < P; ++k) {
             const int p = tid + k * cx.nthr;
-            if (nseg < 1 || sg[0].kind != SK_L || p >= sg[0].tbeg + sg[0].span) break;          // (the loglambda segment comes first: later slots hold unit pairs only)
-            BRSt<1> st;
-            br_desc<KIND, 1, false, (TT + 1) / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0, lds);
+            if (p >= lspan) break;          // (the loglambda segment comes first: later slots hold unit pairs only)
+            BRSt<1>& st = g.st;
+            br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0, lds);
             const int meta = st.meta[0];
             if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
-            const double* zb = lds + Y.zl + st.zoff[0];
+            const bb_d2 d = *(const bb_d2*)(lds + Y.zl + 2 * (p - sg[0].tbeg));
             const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
-            const double z0 = zb[0], z1 = zb[1];
-            const double zn = hn ? zb[2] : z1;
-            double dm = z1 - z0, dn = zn - z1;
+            double dm = d.x, dn = d.y;
             if (mut) {
                 double sm, sn, wm, wn;
-                br_unit_sw<KIND>(lds, Y, 0, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
-                if (KIND == 1) br_unit_sw<KIND>(lds, Y, 0, st.uo[0][2], 0, &sn, &wn);
+                br_unit_sw<KIND>(lds, Y, buf, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
+                if (KIND == 1) br_unit_sw<KIND>(lds, Y, buf, st.uo[0][2], 0, &sn, &wn);
                 else { sn = sm; wn = wm; }
                 dm -= sm; dn -= sn;
-                acc.cv[1] += wm; acc.cv[2] += wm * dm; acc.cv[3] += wm * dm * dm;
-                if (hn) { acc.cv[7] += wn; acc.cv[8] += wn * dn; acc.cv[9] += wn * dn * dn; }
+                g.cv[1] += wm; g.cv[2] += wm * dm; g.cv[3] += wm * dm * dm;
+                if (hn) { g.cv[7] += wn; g.cv[8] += wn * dn; g.cv[9] += wn * dn * dn; }
             } else {
-                acc.cv[4] += dm; acc.cv[5] += dm * dm;
-                if (hn) { acc.cv[10] += dn; acc.cv[11] += dn * dn; }
+                g.cv[4] += dm; g.cv[5] += dm * dm;
+                if (hn) { g.cv[10] += dn; g.cv[11] += dn * dn; }
             }
         }
 #ifndef BB_EMU
@@ -179,7 +253,7 @@ BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
         const int lane16 = tid & 15, row = tid >> 4;
 #pragma unroll
         for (int q = 0; q < BR_NCV; ++q) {
-            const double v = bs_class_sum<LPB>(acc.cv[q]);
+            const double v = bs_class_sum<LPB>(g.cv[q]);
             if (lane16 < LPB) lds[Y.racc_r[0] + q * stride + row * LPB + lane16] = v;
         }
 #endif
@@ -190,67 +264,183 @@ BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
         if (lane16 < LPB) {
             for (int q = 0; q < BR_NCV; ++q) {
                 double v = 0.0;
-                for (int i = lane16; i < 16; i += LPB) v += BB_PSTATE(accv, (tid & ~15) + i).cv[q];
+                for (int i = lane16; i < 16; i += LPB) v += BB_PSTATE(gv, (tid & ~15) + i).cv[q];
                 lds[Y.racc_r[0] + q * stride + row * LPB + lane16] = v;
             }
         }
     }
 #endif
-    BB_SYNC(cx);                     // barrier 2: the partial sums are in LDS
+    BB_SYNC(cx);                     // barrier: the partial sums are in LDS
 }
 
-// likelihood gradient of the two latents of a unit pair (the unit branch of br_update, one slot): the sums over the time steps that use
-// the unit, As = w sum r, Qs = w sum r^2 - n, r = dl - s_eff - c_t
-template <int KIND, int TT>
-BB_DEV void bs_unit_grad(double* lds, const DevModel& M, const BRLay& Y, const BRSt<1>& st, int kind, bool a0, bool a1, double* g0, double* g1, double* z0, double* z1) {
-    const BBLds& L = Y.L;
-    const int* envt = (const int*)(lds + Y.envt);
-    const double* stg = lds;
-    const double* zbuf = lds + Y.zl;
-    const int E = KIND == 1 ? M.E : 1;
-    double gx[2] = {0.0, 0.0}, zx[2] = {0.0, 0.0};
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        if (!(x ? a1 : a0)) continue;
-        const int j = st.zoff[0] + x;                      // stage index of the latent
-        const int e = KIND == 2 ? 0 : (st.uo[0][2] >> (8 * x)) & 255, bl = st.uo[0][x];
-        zx[x] = stg[BR_ST(Y, br_stage_raw<KIND>(kind)) + j];
-        const int th = KIND <= 1 ? 0 : j - ((st.uo[0][2] >> (16 * x)) & 0xffff);
-        double sv, wv;
-        br_unit_sw<KIND>(lds, Y, 0, j, th, &sv, &wv);
-        const double* zr = zbuf + Y.zr0[0] + bl * (TT + 1);
-        double As = 0.0, Qs = 0.0;
-        int nn = 0;
-        double zrow[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) zrow[tt] = zr[tt];          // the whole row in flight at once
-#pragma unroll
-        for (int tt = 0; tt < TT - 1; ++tt) {
-            const bool use = E == 1 || envt[tt + 1] == e;
-            const double rr = use ? (zrow[tt + 1] - zrow[tt]) - sv - lds[L.cc + tt] : 0.0;
-            As += rr; Qs += rr * rr; nn += use ? 1 : 0;
-        }
-        double acc;
-        if (KIND <= 1) acc = kind == SK_S ? wv * As : wv * Qs - (double)nn;
-        else if (kind == SK_LS_R) acc = wv * Qs - (double)nn;
-        else if (kind == SK_TT_R) {
-            acc = wv * As * stg[BR_ST(Y, 1) + j];                                            // e^{logtau}
-            lds[Y.gas + j] = wv * As;                                                        // d/ds_eff: its genotype's theta sums these
-        } else acc = wv * As * stg[BR_ST(Y, 1) + j] * stg[BR_ST(Y, 0) + j];                  // logtau: e^{logtau} theta_tilde
-        gx[x] = acc;
+// state of a pair and its window slot in; out again
+BB_DEV void bs_load_state(const DevModel& M, const DevState& S, const double* hs_m, const double* hs_o, long long i0, long long ih, bool a0, bool a1, BSG& g) {
+    g.mu = br_load_pair<false>(S.mu, i0, a0, a1); g.om = br_load_pair<false>(S.om, i0, a0, a1);
+    g.am = br_load_pair<false>(S.acc_mu, i0, a0, a1); g.ao = br_load_pair<false>(S.acc_om, i0, a0, a1);
+    g.lo = bb_load_lo(S, i0, a0, a1);
+    g.hm = g.ho = bb_d2{0, 0};
+    if (hs_m) {
+#if !defined(BB_EMU) && BS_NT_HIST
+        if (a0 && a1) {
+            typedef double bs_v2d __attribute__((ext_vector_type(2)));
+            const bs_v2d x = __builtin_nontemporal_load((const bs_v2d*)(hs_m + ih)), y = __builtin_nontemporal_load((const bs_v2d*)(hs_o + ih));
+            g.hm = bb_d2{x.x, x.y}; g.ho = bb_d2{y.x, y.y};
+        } else
+#endif
+        { g.hm = br_load_pair<false>(hs_m, ih, a0, a1); g.ho = br_load_pair<false>(hs_o, ih, a0, a1); }
     }
-    *g0 = gx[0]; *g1 = gx[1]; *z0 = zx[0]; *z1 = zx[1];
+}
+// optimiser update of the pair from the likelihood + prior gradient (g0, g1) and the draw's a = eps sigmoid, h = sigmoid / softplus; stores
+BB_DEV bool bs_apply_store(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot wslot, double* hs_m, double* hs_o,
+                           long long i0, long long ih, bool a0, bool a1, double g0, double g1, BSG& g) {
+    const double go0 = fma(g0, g.e.x * g.sg.x, g.sg.x * bb_rcp(g.sp.x)), go1 = fma(g1, g.e.y * g.sg.y, g.sg.y * bb_rcp(g.sp.y));
+    bb_d2 nhm = g.hm, nho = g.ho;
+    if (a0) {
+        bb_opt_apply(M, S, A, wslot, 0, ih, -g0, g.hm.x, &nhm.x, &g.mu.x, &g.am.x, &g.lo.x);
+        bb_opt_apply(M, S, A, wslot, 1, ih, -go0, g.ho.x, &nho.x, &g.om.x, &g.ao.x, &g.lo.y);
+    }
+    if (a1) {
+        bb_opt_apply(M, S, A, wslot, 0, ih + 1, -g1, g.hm.y, &nhm.y, &g.mu.y, &g.am.y, &g.lo.z);
+        bb_opt_apply(M, S, A, wslot, 1, ih + 1, -go1, g.ho.y, &nho.y, &g.om.y, &g.ao.y, &g.lo.w);
+    }
+    br_store_pair<false>(S.mu, i0, a0, a1, g.mu);
+    br_store_pair<false>(S.om, i0, a0, a1, g.om);
+    br_store_pair<false>(S.acc_mu, i0, a0, a1, g.am);
+    br_store_pair<false>(S.acc_om, i0, a0, a1, g.ao);
+    bb_store_lo(S, i0, a0, a1, g.lo);
+    if (hs_m) { br_store_pair_stream<false>(hs_m, ih, a0, a1, nhm); br_store_pair_stream<false>(hs_o, ih, a0, a1, nho); }
+    const double chk = (a0 ? g.mu.x + g.om.x : 0.0) + (a1 ? g.mu.y + g.om.y : 0.0);
+    return !(chk - chk == 0.0);
 }
 
-// ---- G: every pair slot -- state and window slot in, the draw again, gradient, optimiser, everything out -----------------------
+// ---- G-L: every loglambda pair slot -- state in, the draw again, gradient, the barcode's unit sums, optimiser, out; the next sample ----
 template <int KIND, int TT>
-BB_DEV void bs_update(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any) {
+BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv) {
+    double* lds = cx.lds;
+    const BBLds& L = Y.L;
+    constexpr int LPB = TT / 2;
+    const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
+    const int g0t = KIND == 2 ? S.tile_g[cx.block] : 0, g1t = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
+    const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
+    const int nseg = ((const int*)(lds + L.misc))[0];
+    const int lspan = bs_lspan(sg, nseg), buf = (int)(step & 1u);
+    const int PL = (lspan + cx.nthr - 1) / cx.nthr;           // slots with loglambda pairs: the same for every thread (DPP needs whole waves)
+    const int E = KIND == 1 ? M.E : 1;
+    double* hs_m = nullptr;
+    double* hs_o = nullptr;
+    if (A.opt == 0) {
+        hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dh;
+        hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dh;
+    }
+    double* aq = lds + Y.hbuf;            // [SU] pairs (As, Qs) per unit, in the moment contributions' region (dead since the row sums)
+    for (int k = 0; k < PL; ++k) {
+        // A: state in, the step's draw again, the sample
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+            const int p = tid + k * cx.nthr;
+            g.ok = 0;
+            g.z = bb_d2{0.0, 0.0};
+            g.xa = g.xq = g.rm = g.rn = 0.0;
+            if (p < lspan) {
+                br_desc<KIND, 1, false, TT / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, g.st, 0, lds);
+                if (g.st.meta[0] & BRM_VALID) {
+                    g.ok = 1;
+                    const long long i0 = g.st.i0[0];
+                    bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[0].pad, true, true, g);
+                    g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
+                    g.z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);
+                }
+            }
+        }
+        // B: the neighbour pairs' samples, differences, residuals, gradient
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+            const double zpv = BS_PREV(gv, tid, z.y), znv = BS_NEXT(gv, tid, z.x);
+            if (g.ok) {
+                const BRSt<1>& st = g.st;
+                const int meta = st.meta[0], pt = st.pt[0];
+                const bool hp = meta & BRM_PREV, hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+                const double z0 = g.z.x, z1 = g.z.y;
+                const double zp = hp ? zpv : z0, zn = hn ? znv : z1;
+                double ap = z0 - zp, am = z1 - z0, an = zn - z1, wp, wm, wn;
+                if (mut) {
+                    double sp_, sm, sn;
+                    br_unit_sw<KIND>(lds, Y, buf, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
+                    if (KIND == 1) {
+                        br_unit_sw<KIND>(lds, Y, buf, st.uo[0][0], 0, &sp_, &wp);
+                        br_unit_sw<KIND>(lds, Y, buf, st.uo[0][2], 0, &sn, &wn);
+                    } else { sp_ = sn = sm; wp = wn = wm; }
+                    ap -= sp_; am -= sm; an -= sn;
+                } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
+                const double cp = hp ? lds[L.cc + pt - 1] : 0.0, cm = lds[L.cc + pt], cn = hn ? lds[L.cc + pt + 1] : 0.0;
+                const double rm = am - cm, rn = hn ? an - cn : 0.0;          // residuals of the pair's own two forward differences
+                const double rp_ = hp ? wp * (ap - cp) : 0.0, rm_ = wm * rm, rn_ = hn ? wn * rn : 0.0;
+                double pm0, iv0, pm1, iv1;
+                br_pair_prior<KIND>(lds, Y, st, 0, true, true, &pm0, &iv0, &pm1, &iv1);
+                const double l0 = bb_exp(z0), l1 = bb_exp(z1);
+                g.g0 = ((double)st.cnt[0][0] - l0) + l0 * lds[Y.iG + pt] + rm_ - rp_ - (z0 - pm0) * iv0;
+                g.g1 = ((double)st.cnt[0][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn_ - rm_ - (z1 - pm1) * iv1;
+                g.rm = mut ? rm : 0.0;
+                g.rn = mut ? rn : 0.0;
+            }
+        }
+        // C: the barcode's unit sums As = sum_t r, Qs = sum_t r^2 over the time steps that use the unit (multienv: per environment) --
+        // the lanes of a barcode add up, its first lane stores
+        for (int e = 0; e < E; ++e) {
+            BB_PASS(cx, tid) {
+                BSG& g = BB_PSTATE(gv, tid);
+                // (stage index of a unit = mutant x E + environment: the difference t0 uses the unit uo[1], t0 + 1 the unit uo[2])
+                const bool um = g.ok && (g.st.meta[0] & BRM_MUT) && (E == 1 || g.st.uo[0][1] % E == e);
+                const bool un = g.ok && (g.st.meta[0] & BRM_MUT) && (g.st.meta[0] & BRM_NEXT) && (E == 1 || g.st.uo[0][2] % E == e);
+                g.xa = (um ? g.rm : 0.0) + (un ? g.rn : 0.0);
+                g.xq = (um ? g.rm * g.rm : 0.0) + (un ? g.rn * g.rn : 0.0);
+            }
+            BB_PASS(cx, tid) {
+                BSG& g = BB_PSTATE(gv, tid);
+                const double As = BS_GROUP_SUM(LPB, gv, tid, xa), Qs = BS_GROUP_SUM(LPB, gv, tid, xq);
+                const int p = tid + k * cx.nthr;
+                if (g.ok && (g.st.meta[0] & BRM_MUT) && ((p - sg[0].tbeg) & (LPB - 1)) == 0) {
+                    const int u = g.st.uo[0][1] - (E > 1 ? g.st.uo[0][1] % E : 0) + e;          // stage index of unit (mutant, e)
+                    *(bb_d2*)(aq + 2 * u) = bb_d2{As, Qs};
+                }
+            }
+        }
+        // D: optimiser, everything out; then the NEXT step's sample of the updated pair
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+            g.z = bb_d2{0.0, 0.0};
+            if (g.ok) {
+                const long long i0 = g.st.i0[0];
+                if (bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, i0 - sg[0].pad, true, true, g.g0, g.g1, g)) *bad_any = 1;
+                const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
+                g.z = bs_z(g.mu, g.om, en, &g.sp, &g.sg);
+            }
+        }
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+            const double zn = BS_NEXT(gv, tid, z.x);
+            const int p = tid + k * cx.nthr;
+            if (g.ok) bs_put_l(lds, Y, p - sg[0].tbeg, g.st.meta[0], g.z, zn, g);
+        }
+    }
+    BB_STAMP(cx, S, 27);
+    BB_SYNC(cx);                     // the units' sums are in LDS
+}
+
+// ---- G-U: the unit pair slots (and the replicated global latents on tile 0) ----------------------------------------------------------
+template <int KIND, int TT>
+BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
     const int g0t = KIND == 2 ? S.tile_g[cx.block] : 0, g1t = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
+    const int lspan = bs_lspan(sg, nseg), buf = (int)(step & 1u), nbuf = buf ^ 1;
+    const int E = KIND == 1 ? M.E : 1;
+    const int* envt = (const int*)(lds + Y.envt);
+    const double* aq = lds + Y.hbuf;
+    const double* stg = lds + buf * Y.SU;
     double* hs_m = nullptr;
     double* hs_o = nullptr;
     if (A.opt == 0) {
@@ -263,97 +453,77 @@ BB_DEV void bs_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     for (int pass = 0; pass < (KIND == 2 ? 2 : 1); ++pass) {
         if (pass) BB_SYNC(cx);
         BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
             bool bad = false;
-            for (int k = 0; k < P; ++k) {
+            for (int k = lspan / cx.nthr; k < P; ++k) {
                 const int p = tid + k * cx.nthr;
+                if (p < lspan) continue;
                 if (KIND == 2 && ((p >= th_lo && p < th_hi) != (pass == 1))) continue;      // (the theta segment's pairs: pass 1, everything else: pass 0)
-                BRSt<1> st;
-                br_desc<KIND, 1, false, (TT + 1) / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
+                BRSt<1>& st = g.st;
+                br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
                 const int meta = st.meta[0];
                 if (!(meta & BRM_VALID)) continue;
                 const int kind = meta & 15;
                 const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-                const long long i0 = st.i0[0];
-                bb_d2 mu = br_load_pair<false>(S.mu, i0, a0, a1), om = br_load_pair<false>(S.om, i0, a0, a1);
-                bb_d2 am = br_load_pair<false>(S.acc_mu, i0, a0, a1), ao = br_load_pair<false>(S.acc_om, i0, a0, a1);
-                bb_f4 lo = bb_load_lo(S, i0, a0, a1);
-                bb_d2 hm{0, 0}, ho{0, 0};
-                const long long ih = i0 - sg[meta >> 12].pad;
-                if (hs_m) {
-#if !defined(BB_EMU) && BS_NT_HIST
-                    if (a0 && a1) {
-                        typedef double bs_v2d __attribute__((ext_vector_type(2)));
-                        const bs_v2d x = __builtin_nontemporal_load((const bs_v2d*)(hs_m + ih)), y = __builtin_nontemporal_load((const bs_v2d*)(hs_o + ih));
-                        hm = bb_d2{x.x, x.y}; ho = bb_d2{y.x, y.y};
-                    } else
-#endif
-                    { hm = br_load_pair<false>(hs_m, ih, a0, a1); ho = br_load_pair<false>(hs_o, ih, a0, a1); }
-                }
-                // the draw of the S pass again (a pure function of seed, latent and step), and what of it the omega gradient needs
-                bb_d2 av, hv;
-                if (BS_KEEP_AH) {
-                    av = br_load_pair<false>(S.asv, i0, a0, a1);
-                    hv = br_load_pair<false>(S.hsv, i0, a0, a1);
-                } else {
-                    const bb_d2 e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
-                    double sp0, sg0, sp1, sg1;
-                    bb_softplus_sigmoid(om.x, &sp0, &sg0);
-                    bb_softplus_sigmoid(om.y, &sp1, &sg1);
-                    av = bb_d2{e.x * sg0, e.y * sg1};
-                    hv = bb_d2{sg0 * bb_rcp(sp0), sg1 * bb_rcp(sp1)};
-                }
-                double pm0 = 0.0, pm1 = 0.0, iv0 = 0.0, iv1 = 0.0;
-                double g0 = 0.0, g1 = 0.0, z0 = 0.0, z1 = 0.0;
-                if (kind == SK_L) {
-                    const double* zb = lds + Y.zl + st.zoff[0];
-                    st.lam[0] = bb_d2{bb_exp(zb[0]), bb_exp(zb[1])};
-                    br_l_grad<KIND, 1, false, false>(lds, Y, st, 0, 0, &g0, &g1);      // (prior term included)
-                } else {
-                    br_pair_prior<KIND>(lds, Y, st, 0, a0, a1, &pm0, &iv0, &pm1, &iv1);
-                    if (KIND == 2 && kind == SK_TH_R) {
+                const long long i0 = st.i0[0], ih = i0 - sg[meta >> 12].pad;
+                bs_load_state(M, S, hs_m, hs_o, i0, ih, a0, a1, g);
+                g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
+                const bb_d2 z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);          // the owner's own sample of this step, again
+                double pm0, iv0, pm1, iv1, gl0 = 0.0, gl1 = 0.0;
+                br_pair_prior<KIND>(lds, Y, st, 0, a0, a1, &pm0, &iv0, &pm1, &iv1);
+                if (KIND == 2 && kind == SK_TH_R) {
 #pragma unroll
-                        for (int x = 0; x < 2; ++x) {
-                            if (!(x ? a1 : a0)) continue;
-                            const int first = st.uo[0][x] & 0xffff, n = st.uo[0][x] >> 16;
-                            double s = 0.0;
-                            for (int i = 0; i < n; ++i) s += lds[Y.gas + first + i];
-                            (x ? g1 : g0) = s;
-                            (x ? z1 : z0) = lds[BR_ST(Y, 3) + st.zoff[0] + x];
-                        }
-                    } else if (kind < SK_GS) {
-                        bs_unit_grad<KIND, TT>(lds, M, Y, st, kind, a0, a1, &g0, &g1, &z0, &z1);
-                    } else {
-                        const double* gg = lds + L.gglob + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
-                        const double* zz = lds + L.zgl + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
-                        if (a0) { g0 = gg[0]; z0 = zz[0]; }
-                        if (a1) { g1 = gg[1]; z1 = zz[1]; }
+                    for (int x = 0; x < 2; ++x) {
+                        if (!(x ? a1 : a0)) continue;
+                        const int first = st.uo[0][x] & 0xffff, n = st.uo[0][x] >> 16;
+                        double s = 0.0;
+                        for (int i = 0; i < n; ++i) s += lds[Y.gas + first + i];
+                        (x ? gl1 : gl0) = s;
                     }
-                    g0 -= (z0 - pm0) * iv0;
-                    g1 -= (z1 - pm1) * iv1;
+                } else if (kind < SK_GS) {
+                    // Per unit u = (mutant [, environment]) the sums over the time steps that use it, As = sum r, Qs = sum r^2 (the loglambda
+                    // lanes left them), give d/ds_bc = w As, d/dlogsigma = w Qs - n; hierarchical: s_eff = theta + e^{logtau} theta_tilde, so
+                    // d/dtheta_tilde = w As e^{logtau}, d/dlogtau = w As e^{logtau} theta_tilde, d/dtheta = sum over the genotype of w As
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        if (!(x ? a1 : a0)) continue;
+                        const int j = st.zoff[0] + x;                      // stage index of the latent's unit
+                        const bb_d2 AQ = *(const bb_d2*)(aq + 2 * j);
+                        const double wv = stg[BR_ST(Y, KIND <= 1 ? 1 : 2) + j];
+                        int nn = TT - 1;
+                        if (E > 1) { const int e = (st.uo[0][2] >> (8 * x)) & 255; nn = 0; for (int tt = 0; tt < TT - 1; ++tt) nn += envt[tt + 1] == e ? 1 : 0; }
+                        double acc;
+                        if (KIND <= 1) acc = kind == SK_S ? wv * AQ.x : wv * AQ.y - (double)nn;
+                        else if (kind == SK_LS_R) acc = wv * AQ.y - (double)nn;
+                        else if (kind == SK_TT_R) {
+                            acc = wv * AQ.x * stg[BR_ST(Y, 1) + j];                                          // e^{logtau}
+                            lds[Y.gas + j] = wv * AQ.x;                                                      // d/ds_eff: its genotype's theta sums these
+                        } else acc = wv * AQ.x * stg[BR_ST(Y, 1) + j] * stg[BR_ST(Y, 0) + j];                // logtau: e^{logtau} theta_tilde
+                        (x ? gl1 : gl0) = acc;
+                    }
+                } else {
+                    const double* gg = lds + L.gglob + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
+                    if (a0) gl0 = gg[0];
+                    if (a1) gl1 = gg[1];
                 }
-                const double go0 = fma(g0, av.x, hv.x), go1 = fma(g1, av.y, hv.y);
-                bb_d2 nhm = hm, nho = ho;
-                if (a0) {
-                    bb_opt_apply(M, S, A, wslot, 0, ih, -g0, hm.x, &nhm.x, &mu.x, &am.x, &lo.x);
-                    bb_opt_apply(M, S, A, wslot, 1, ih, -go0, ho.x, &nho.x, &om.x, &ao.x, &lo.y);
+                // (the replicated global latents' sample is rank 0's draw, back with the totals; on one GPU that is this thread's own)
+                double zv0 = z.x, zv1 = z.y;
+                if (kind >= SK_GS) {
+                    const double* zz = lds + L.zgl + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
+                    if (a0) zv0 = zz[0];
+                    if (a1) zv1 = zz[1];
                 }
-                if (a1) {
-                    bb_opt_apply(M, S, A, wslot, 0, ih + 1, -g1, hm.y, &nhm.y, &mu.y, &am.y, &lo.z);
-                    bb_opt_apply(M, S, A, wslot, 1, ih + 1, -go1, ho.y, &nho.y, &om.y, &ao.y, &lo.w);
-                }
-                br_store_pair<false>(S.mu, i0, a0, a1, mu);
-                br_store_pair<false>(S.om, i0, a0, a1, om);
-                br_store_pair<false>(S.acc_mu, i0, a0, a1, am);
-                br_store_pair<false>(S.acc_om, i0, a0, a1, ao);
-                bb_store_lo(S, i0, a0, a1, lo);
-                if (hs_m) { br_store_pair_stream<false>(hs_m, ih, a0, a1, nhm); br_store_pair_stream<false>(hs_o, ih, a0, a1, nho); }
-                const double chk = (a0 ? mu.x + om.x : 0.0) + (a1 ? mu.y + om.y : 0.0);
-                bad = bad || !(chk - chk == 0.0);
+                gl0 -= (zv0 - pm0) * iv0;
+                gl1 -= (zv1 - pm1) * iv1;
+                bad = bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, ih, a0, a1, gl0, gl1, g) || bad;
+                // the NEXT step's sample of the updated pair, staged for the other threads
+                const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
+                bs_put_u<KIND>(lds, M, Y, A, st, nbuf, bs_z(g.mu, g.om, en, &g.sp, &g.sg));
             }
             if (bad) *bad_any = 1;
         }
     }
-    BB_SYNC(cx);                     // the step's LDS tables are free: the next S pass rewrites them
+    BB_SYNC(cx);                     // the next step's tables are complete
     BB_STAMP(cx, S, 28);
 }
 
@@ -375,21 +545,22 @@ __global__ void __launch_bounds__(NT) k_stream(const DevModel* __restrict__ Mp, 
     if (threadIdx.x == 0) *bad_any = 0;
     __syncthreads();
     const bool dead = *ok_slot == 0;
-    BSAcc acc;
+    BSG g;
     BRSt<1>* nost = nullptr;
     int done = 0;
     if (!dead) {
+        bs_sample0<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step0, &g);
         BBSlotCtr sc = bb_slot_init(A, step0);
         for (; done < nsteps; ++done, bb_slot_next(A, sc)) {
             const unsigned long long step = step0 + (unsigned long long)done;
             const BBSlot wslot = bb_slot_now(A, sc);
-            bs_sample<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, &acc);
-            bs_moments<KIND, TT>(cx, M, S, A, Y, NB, P, &acc);
+            bs_moments<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, &g);
             br_row_publish<1, true, false>(cx, M, S, Y, nost, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_lead<false>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, 1, false, false>(cx, M, S, A, Y, nost, step, ok_slot);
             if (*ok_slot == 0) break;
-            bs_update<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any);
+            bs_update_l<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any, &g);
+            bs_update_u<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any, &g);
         }
     }
     if (threadIdx.x == 0) {

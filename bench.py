@@ -150,6 +150,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()              # (the barrier is itself GPU work)
 
+    # Timed region at N > 1: all ranks leave ONE barrier together (fence), every rank then times its own K steps
+    # up to its own device being idle, and the job's time is the MAX over the ranks -- the moment the last rank has finished, which is
+    # what a closing barrier would see LESS the barrier's own cost (gloo: ~100 us of TCP, RCCL: a kernel launch and a ring; a 20-step
+    # region is ~300 us).  The MAX is formed after the clocks have stopped; every rank's own time is printed (`rank_ms`).
+
     if exchange == "p2p":
         # first resident launches under a vote: a rank that times out must not leave the others behind on another path
         ok = True
@@ -173,11 +178,15 @@ def main():
         eng.run(args.steps)      # returns after the engine's stream has drained
     except bb._capi.BarBayNonFinite as err:       # the steps were taken; reported below as posterior_finite = false
         print(f"[rank {rank}] {err}", file=sys.stderr, flush=True)
-    fence()
+    torch.cuda.synchronize()                      # (bb_run has drained the engine's stream already; this closes the bracket on torch's side)
     dt = time.perf_counter() - t0
+    rank_ms = [round(dt * 1e3, 4)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        every = [None] * world
+        dist.all_gather_object(every, dt)
+        rank_ms = [round(x * 1e3, 4) for x in every]
         dt = float(t.item())
     st = eng.stats()
     mu, sigma = eng.posterior()
@@ -200,9 +209,7 @@ def main():
         launch_s = st["last_run_ms"] * 1e-3 / launches
         ach = st["bytes_per_step"] * steps_per_launch / launch_s / 1e9
         kname = {1: "k_persist", 2: "k_res", 3: "k_stream"}.get(int(st.get("resident_kernel", 1)), "k_persist")
-        nt = int(st["block_threads"])
-        nt_inst = 1024 if nt > 512 else (512 if (nt > 256 or kname == "k_persist") else 256)
-        roofline = {"bound": "hbm", "kernel": kname, "kernel_instance": f"{kname}<{bb._capi.BB_MODEL[wl.kind]}, {int(st['persistent_pairs'])}, {nt_inst}",
+        roofline = {"bound": "hbm", "kernel": kname, "kernel_instance": eng.kernel_name(),      # (the library names the template instance it launches: bb_kernel_name)
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": int(st["bytes_per_step"] * steps_per_launch),
@@ -225,8 +232,6 @@ def main():
                                                    "algorithmic_bytes_per_launch": int(sp["bytes_sample"])}}}
     if roofline is not None and world > 1:
         roofline["scope"] = "rank 0's GPU and its shard of the bytes"
-        if exchange == "p2p":
-            roofline["kernel_instance"] += ", cross-GPU exchange"
     if roofline is not None and world == 1:
         # `traffic` is NOT measured in this run (PMC counters need rocprofv3 around the process): it is REPLAYED from the last
         # committed counter passes of the same kernel, and only while the device sources are still the ones profiled
@@ -258,8 +263,6 @@ def main():
         if why:
             roofline["traffic_source"] = f"none ({why})"
 
-    if roofline is not None and "kernel_instance" in roofline:
-        roofline["kernel_instance"] += ", ...>"        # (leading template arguments: model kind, pair slots per thread, threads)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
@@ -273,6 +276,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "rank_ms": rank_ms,                       # every rank's own time over the K steps; value uses their MAX
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -282,7 +286,7 @@ def main():
                        "n_latents": int(st["n_latents"]), "samples_per_step": 1,
                        # which path ran on rank 0 (0: two kernels per step, 1: k_persist, 2: k_res, 3: k_stream), its instance and grid
                        "resident_kernel": int(st.get("resident_kernel", 0)),
-                       "kernel_instance": (roofline or {}).get("kernel_instance", "k_sample + k_update (two kernels per step)"),
+                       "kernel_instance": eng.kernel_name(),
                        "tiles_per_rank": int(st["n_blocks"]), "threads_per_tile": int(st["block_threads"]),
                        "optimizer": "TruncatedADAGrad(0.1, 40, 100)", "sharding": f"barcodes/{world}",
                        "collective": "none" if world == 1 else (

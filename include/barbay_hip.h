@@ -120,8 +120,12 @@ typedef struct bb_advi_opts {
     int32_t steps_per_graph;  /* steps captured per hipGraph (0 = default, <0 = eager)   */
     int32_t elbo_every;       /* evaluate the ELBO every k-th step (0 = never)           */
     int32_t launch_mode;      /* 0 = auto; 1 = two kernels per sample (graph / eager);
-                                 2 = one resident launch with a grid barrier per step (S = 1,
-                                 single GPU, no ELBO recording; error if not eligible)     */
+                                 2 = ONE resident launch for the whole step loop (k_res /
+                                 k_stream / k_persist, bb_stats.resident_kernel; the exchange
+                                 of the moment rows runs inside it) -- on one GPU also with
+                                 samples_per_step > 1 and ELBO recording (k_res's MS
+                                 instances), on a sharded handle with the rows pushed into
+                                 the peers' inboxes; error if the shape has no such launch  */
     int32_t n_devices;        /* > 1: ONE handle drives this many GPUs from the calling host
                                  thread: the barcodes shard over the devices,
                                  the resident launches run concurrently and exchange their
@@ -194,6 +198,10 @@ int bb_get_permutation(bb_handle* h, int64_t* caller_index);
 /* AdvancedVI.optimize!: n_steps iterations of
  *   grad(-ELBO) with S reparameterised samples -> optimiser -> theta -= delta. */
 int bb_run(bb_handle* h, int64_t n_steps);
+/* After BB_ERR_DEVICE from a resident launch (an exchange timed out: bb_last_error says so) the handle's step counter is the
+ * device's, but a step may have been left half-way: with samples_per_step > 1 the gradient sums of the samples already taken are
+ * discarded and that step's exchange numbers are issued again.  Re-initialise (bb_init_meanfield / bb_set_params) or set
+ * launch_mode = 1 before running on; a retry without either is deterministic but unspecified.  BB_ERR_NONFINITE: the steps were taken. */
 /* Same arithmetic, launched eagerly with a HIP event pair around every kernel
  * so that per-kernel durations can be reported (bb_stats.avg_*_ms). */
 int bb_run_profiled(bb_handle* h, int64_t n_steps);
@@ -255,6 +263,10 @@ int bb_debug_normals(bb_handle* h, int64_t step, uint32_t stream, int64_t lo, in
 int bb_debug_stamps(bb_handle* h, uint64_t* out, int64_t n);
 
 int bb_get_stats(bb_handle* h, bb_stats* out);
+/* The kernel bb_run launches on this handle, as text: the selected template instance with its arguments in declaration order --
+ * "k_res<KIND,P,NT,XG,TT,AP,MS>" (bb_resident.h), "k_stream<KIND,NT,TT>" (bb_stream.h), "k_persist<KIND,P,NT[,XG]>" (bb_persist.h) --
+ * or "k_sample<KIND> + k_update<KIND>" for the two-kernel step.  buf: [len], always terminated.  No reference counterpart. */
+int bb_kernel_name(bb_handle* h, char* buf, int64_t len);
 
 /* ---- sharded execution -------------------------------------------------------------
  * Barcodes shard over world_size handles (one process per GPU).  Per MC sample the

@@ -112,7 +112,7 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
             samples_per_step::Int=1, max_iters::Int=10_000,
             optimizer::Symbol=:TruncatedADAGrad, eta=0.1, tau=40.0, n=100, pre=1.0, post=0.9,
             priors::Dict{Symbol,<:Any}=Dict{Symbol,Any}(), envs=nothing, genotypes=nothing,
-            seed::Integer=0, device::Integer=0, devices::Vector{<:Integer}=Int[], hier_samples::Integer=10_000)
+            seed::Integer=0, device::Integer=0, devices::Vector{<:Integer}=Int[], hier_samples::Integer=10_000, verbose::Bool=false)
     mats = R isa Vector ? R : (ndims(R) == 3 ? [R[:, :, r] for r in axes(R, 3)] : [R])
     tots = n_t isa Vector{<:Vector} ? n_t : (ndims(n_t) == 2 ? [n_t[:, r] for r in axes(n_t, 2)] : [n_t])
     n_time = Int32[size(m, 1) for m in mats]
@@ -152,6 +152,11 @@ function vi(model_name::String, R, n_t, n_neutral::Int, n_bc::Int;
         check(ccall((:bb_create, LIB), Cint, (Ref{bb_model_desc}, Ref{bb_advi_opts}, Ref{Ptr{Cvoid}}), md, opts, h))
     end
     try
+        if verbose      # (`BarBay.vi.advi(...; verbose)`, src/vi.jl:122-124): which kernel the run launches -- bb_kernel_name
+            nm = Vector{UInt8}(undef, 128)
+            check(ccall((:bb_kernel_name, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64), h[], nm, 128))
+            @info "BarBayHIP: " * unsafe_string(pointer(nm))
+        end
         check(ccall((:bb_run, LIB), Cint, (Ptr{Cvoid}, Int64), h[], max_iters))
         D = ccall((:bb_num_latents, LIB), Int64, (Ptr{Cvoid},), h[])
         m, s = Vector{Float64}(undef, D), Vector{Float64}(undef, D)

@@ -248,28 +248,48 @@ def test_owner_computes_launch_hierarchical_trajectory(hip_lib, name, opt):
     assert k == 2 and a < 1e-10 and b < 1e-10, (k, a, b)
 
 
-@pytest.mark.parametrize("cfg", ["C3_replicate", "C4_multienv", "multienv_replicate_even"])
+@pytest.mark.parametrize("cfg", ["C2_fitness", "C3_replicate", "C4_multienv", "C5_rank", "C5_stream", "multienv_replicate_even"])
 def test_baseline_kernel_instance_against_the_oracle_loop(hip_lib, monkeypatch, cfg):
-    """The kernel instance a BASELINE workload runs at full size -- C3: k_res<replicate, 3 pair slots, 512 threads, T = 6>, C4:
-    k_res<multienv, 1, 1024, T = 6> -- on a 2 000-barcode cut with the full-size tile geometry (barcodes per tile, threads),
-    against the LITERAL oracle's ADVI loop (exact window), not only against the two-kernel step."""
+    """The kernel instance a BASELINE workload runs at full size -- C2: k_res<fitness, 1 pair slot, 1024 threads, T = 8> at 198
+    barcodes per tile; C3: k_res<replicate, 3, 512, T = 6>; C4: k_res<multienv, 1, 1024, T = 6>; C5 as one of its eight ranks holds it:
+    k_res<genotype, 1, 1024, T = 8> with whole-genotype tiles of ~117 barcodes; C5 on one GPU: k_stream<genotype, 1024, T = 8> at 782
+    barcodes per tile, 8 tiles -- each on a cut of the problem with the full-size tile geometry (barcodes per tile, threads), against the
+    LITERAL oracle's ADVI loop (exact window), not only against the two-kernel step.  The instance is the library's own word
+    (bb_kernel_name), not inferred from bb_stats."""
     from conftest import make_engine
     from oracle import fixtures
-    if cfg == "C3_replicate":
+    steps = 10
+    if cfg == "C2_fitness":
+        sp = fixtures.synthetic("fitness", B=2000, T=8, n_neutral=40, seed=42)
+        nb, nthr, inst = 198, 1024, "k_res<0,1,1024,false,8,false,false>"          # 50 000 barcodes / 256 tiles, 65 % leaders
+    elif cfg == "C3_replicate":
         sp = fixtures.synthetic("replicate", B=2000, T=6, n_rep=3, n_neutral=40, seed=43)
-        nb, nthr, pairs = 79, 512, 3           # 20 000 barcodes / 256 tiles, 65 % leaders
+        nb, nthr, inst = 79, 512, "k_res<3,3,512,false,6,false,false>"             # 20 000 barcodes / 256 tiles, 65 % leaders
     elif cfg == "C4_multienv":
         sp = fixtures.synthetic("multienv", B=2000, T=6, n_env=4, n_neutral=40, seed=44)
-        nb, nthr, pairs = 79, 1024, 1
+        nb, nthr, inst = 79, 1024, "k_res<1,1,1024,false,6,false,false>"
+    elif cfg == "C5_rank":
+        # 25 000 barcodes of 625 genotypes over ~216 tiles: ~117 barcodes, three genotypes of ~39 mutants per tile
+        sp = fixtures.synthetic("genotype", B=2400, T=8, n_geno=60, n_neutral=48, seed=45, geno_runs=True)
+        nb, nthr, inst = 125, 1024, "k_res<2,1,1024,false,8,false,false>"
+    elif cfg == "C5_stream":
+        # 200 000 barcodes over 256 tiles: 782 barcodes and ~4 300 pairs per tile -- five pair slots per thread, the state streamed
+        sp = fixtures.synthetic("genotype", B=6256, T=8, n_geno=160, n_neutral=126, seed=45, geno_runs=True)
+        nb, nthr, inst = 256, 1024, "k_stream<2,1024,8>"          # (the two-kernel step's own tile; the resident launch's: BB_TUNE_RES_NB)
+        monkeypatch.setenv("BB_TUNE_RES_NB", "800")
+        steps = 8
     else:
         sp = fixtures.synthetic("multienv_replicate", B=1500, T=6, n_rep=2, n_env=3, n_neutral=30, seed=46)
-        nb, nthr, pairs = 60, 512, None
+        nb, nthr, inst = 60, 512, "k_res<4,"
     monkeypatch.setenv("BB_TUNE_NB", str(nb))
     monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
-    e, a, b, _ = c._trajectory(hip_lib, sp, 10, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
-    st = e.stats()
+    e, a, b, _ = c._trajectory(hip_lib, sp, steps, 1, "TruncatedADAGrad", seed=13, window=4, resum_every=1, launch_mode=2)
+    st, name = e.stats(), e.kernel_name()
     e.close()
-    assert st["resident_kernel"] == 2 and st["block_threads"] == nthr and (pairs is None or st["persistent_pairs"] == pairs), st
+    assert name.startswith(inst), name
+    assert st["block_threads"] == nthr and st["resident_kernel"] == (3 if cfg == "C5_stream" else 2), st
+    if cfg == "C5_stream":
+        assert st["n_blocks"] >= 8 and st["persistent_pairs"] >= 5, st
     assert a < 1e-10 and b < 1e-10, (a, b)
 
 

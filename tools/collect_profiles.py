@@ -35,11 +35,18 @@ for src, dst in ((f"{tag}_bench.json", "bench.json"), (f"{tag}_bench20.json", "b
     cp(src, dst)
 for c in ("C3", "C4", "C5rank"):
     cp(f"{tag}_validate_{c}.json", f"validate_{c}_3000_iterations.json")
-# (the traffic record names the COMMITTED directory its counter rows sit in, not the scratch tag)
-_t = json.load(open(os.path.join(G, tag, "hbm_traffic_latest.json")))
-_t["source"] = f"profiles/{name} (bash tools/round_end.sh {tag} -> tools/profile_all.sh; pmc_FETCH_SIZE_k_res.csv, pmc_WRITE_SIZE_k_res.csv)"
-json.dump(_t, open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)
-json.dump(_t, open(os.path.join(D, "hbm_traffic.json"), "w"), indent=1)
+# (the traffic record names the COMMITTED directory its counter rows sit in, not the scratch tag; it is restamped only when this round's
+#  counter passes exist -- a partial round must neither crash the collection nor point bench.py's replayed `traffic` at a directory
+#  without the matching rows: ADVICE r03)
+_tp = os.path.join(G, tag, "hbm_traffic_latest.json")
+_have_rows = all(newest(os.path.join(f"{tag}/{d}", "**", "*counter_collection.csv")) for d in ("pmc_fetch", "pmc_write"))
+if os.path.exists(_tp) and _have_rows:
+    _t = json.load(open(_tp))
+    _t["source"] = f"profiles/{name} (bash tools/round_end.sh {tag} -> tools/profile_all.sh; pmc_FETCH_SIZE_k_res.csv, pmc_WRITE_SIZE_k_res.csv)"
+    json.dump(_t, open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"), "w"), indent=1)
+    json.dump(_t, open(os.path.join(D, "hbm_traffic.json"), "w"), indent=1)
+else:
+    print(f"missing: {_tp if not os.path.exists(_tp) else 'the FETCH / WRITE counter rows'} -- profiles/hbm_traffic_latest.json left as it was")
 for kind in ("kernel_stats", "domain_stats"):
     f = newest(f"{tag}/trace/**/*{kind}.csv")
     if f:

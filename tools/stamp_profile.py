@@ -50,9 +50,9 @@ for lo, hi, title in (((0, 6, "k_sample"), (8, 16, "k_update")) if mode == 1 els
             print(f"      {nm:28s} {np.median(st[:, b] - st[:, a]):9.0f}")
     if mode == 2:
         lead = np.arange(st.shape[0]) < 8
-        print(f"      publish: store + drain + meet {np.median(st[:, 7] - st[:, 24]):.0f}")
-        print(f"      leaders: wait members {np.median(st[lead, 17] - st[lead, 7]):.0f}  (min {(st[lead, 17] - st[lead, 7]).min()})  read+sum+store+drain+flag {np.median(st[lead, 18] - st[lead, 17]):.0f}  then until group rows ready {np.median(st[lead, 1] - st[lead, 18]):.0f}")
-        print(f"      others : until group rows ready {np.median(st[~lead, 1] - st[~lead, 7]):.0f} (min {(st[~lead, 1] - st[~lead, 7]).min()})   read group rows + sum {np.median(st[:, 25] - st[:, 1]):.0f}")
+        # (k_res / k_stream with tagged rows: no drain, no meet, no "members seen": 24 = own row out, 18 = leader's group row out, 1 = group rows seen)
+        print(f"      leaders: own row out -> group row out {np.median(st[lead, 18] - st[lead, 24]):.0f}  then until group rows seen {np.median(st[lead, 1] - st[lead, 18]):.0f}")
+        print(f"      others : own row out -> group rows seen {np.median(st[~lead, 1] - st[~lead, 24]):.0f} (min {(st[~lead, 1] - st[~lead, 24]).min()})   group rows seen -> totals in LDS {np.median(st[:, 25] - st[:, 1]):.0f}")
         arr = st[:, 24] - st[:, 24].min(); rel = st[:, 25] - st[:, 24].min()
         print(f"      arrival spread over tiles: median {np.median(arr):.0f} p90 {np.percentile(arr, 90):.0f} max {arr.max()}   release after first arrival: median {np.median(rel):.0f} max {rel.max()}")
         late = np.argsort(arr)[-5:]

@@ -16,7 +16,8 @@ AB = os.path.join(g.PKG, "lib", "ab")
 if sys.argv[1] == "build":
     os.makedirs(AB, exist_ok=True)
     name, flags = sys.argv[2], sys.argv[3:]
-    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", *g.HIP_FLAGS, "-DBB_FAST_BUILD", *flags, *extra, g.SRC, "-o", os.path.join(AB, name + suf + ".so"), "-ldl"])
+    SRC = os.environ.get("XP_SRC", g.SRC)          # (XP_SRC=/tmp/old/bb_engine.hip: an A/B build of another checkout's sources)
+    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", *g.HIP_FLAGS, "-DBB_FAST_BUILD", *flags, *extra, "-I", os.path.join(ROOT, "include"), SRC, "-o", os.path.join(AB, name + suf + ".so"), "-ldl"])
           for suf, extra in (("", []), ("_st", ["-DBB_STAMPS"]))]
     sys.exit(max(p.wait() for p in ps))
 
@@ -27,6 +28,8 @@ WL = os.environ.get("WL", "fitness_normal")
 wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42) if WL == "fitness_normal" else getattr(synth, WL)()
 names = sys.argv[2:]
 PH = [(20, 21, "S"), (21, 23, "M"), (23, 24, "pub"), (24, 25, "X"), (25, 26, "F"), (26, 28, "G")]
+# k_stream since round 4 (one pass over the state per step: the next sample is formed inside the G passes): a step runs M -> G-U
+PH_STREAM = [(22, 23, "M"), (23, 24, "pub"), (24, 25, "X"), (25, 26, "F"), (26, 27, "G-L"), (27, 28, "G-U")]
 
 
 def engine(lib):
@@ -46,12 +49,15 @@ for rep in range(2):
             e = engine(_capi.load_library(os.path.join(AB, name + "_st.so")))
             e.run(21)
             s = e.stamps().astype(np.int64)
-            tot = np.median(s[:, 28] - s[:, 20])
-            line += f" | span {tot:6.0f}: " + " ".join(f"{nm} {np.median(s[:, b] - s[:, a]):5.0f}" for a, b, nm in PH if s[:, b].any() and s[:, a].any())
+            fused = st["resident_kernel"] == 3 and s[:, 22].any() and s[:, 27].any()
+            tot = np.median(s[:, 28] - s[:, 22 if fused else 20])
+            line += f" | span {tot:6.0f}: " + " ".join(f"{nm} {np.median(s[:, b] - s[:, a]):5.0f}" for a, b, nm in (PH_STREAM if fused else PH) if s[:, b].any() and s[:, a].any())
             lead = np.arange(s.shape[0]) < 8
-            line += (f"\n     leaders: publish->members seen {np.median(s[lead, 17] - s[lead, 24]):.0f}, read+sum+store+flag {np.median(s[lead, 18] - s[lead, 17]):.0f}, "
-                     f"then until group rows seen {np.median(s[lead, 1] - s[lead, 18]):.0f}; others: publish->group rows seen {np.median(s[~lead, 1] - s[~lead, 24]):.0f}, "
-                     f"rows read+sum {np.median(s[:, 25] - s[:, 1]):.0f}; leaders publish earlier than others by {np.median(s[~lead, 24]) - np.median(s[lead, 24]):.0f}")
+            # (tagged rows: a leader polls its members' rows and sums them in one pass -- there is no "members seen" stamp any more; 18 = its
+            #  group row is out, 1 = the group rows have been seen, 24 = the tile's own row is out)
+            line += (f"\n     leaders: own row out -> group row out (poll members' rows + sum + store) {np.median(s[lead, 18] - s[lead, 24]):.0f}, "
+                     f"then until the group rows are seen {np.median(s[lead, 1] - s[lead, 18]):.0f}; others: own row out -> group rows seen {np.median(s[~lead, 1] - s[~lead, 24]):.0f}; "
+                     f"all: group rows seen -> totals in LDS {np.median(s[:, 25] - s[:, 1]):.0f}")
             # wall-clock stamps (100 MHz): publish and totals-seen over all tiles, in shader cycles at ~2.4 GHz
             for ev, nm in ((29, "publish"), (30, "totals seen")):
                 tt = (s[:, ev] - s[:, ev].min()) * 24
