@@ -185,9 +185,10 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     if (stream) {
         // (no normals, no window slot in LDS: they go through registers.  hbuf = the units' sums (As, Qs) [SU] pairs, written by the loglambda
         //  lanes in the G pass -- the contributions are dead by then -- and read by the unit threads)
-        Y.hbuf = Y.eps = Y.racc;
+        Y.hbuf = Y.racc;
         busy = racc_total > 2 * Y.SU ? racc_total : 2 * Y.SU;
         o += busy;
+        Y.eps = o;     o += NT / 2;          // (4 bytes per thread: where the LDS-DMA touches of the first slot's lines land, bs_touch0)
     } else if (own_hbuf) {
         // the window slot is fetched while the moment contributions are alive (RunArgs.pf = 1, 2): a region of its own
         Y.eps = Y.racc;

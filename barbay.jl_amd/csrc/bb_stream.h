@@ -49,8 +49,9 @@ struct BSG {
     bb_d2 mu, om, am, ao, hm, ho;     // state of the pair and its window slot
     bb_f4 lo;
     bb_d2 e, z, sg, sp;               // the step's draw, sample, sigmoid / softplus of omega
+    bb_d2 a, h;                       // eps sigmoid(omega) = dz / domega, sigmoid / softplus = dH / domega
     double g0, g1, zv0, zv1;          // likelihood gradient and sample of the two latents
-    double rm, rn;                    // loglambda, mutant: residuals of the pair's two forward differences
+    double rm, rn, wm;                // loglambda, mutant: residuals of the pair's two forward differences; precision of the unit of the first
     double xa, xq;                    // ... and what of them goes to the unit sums being formed (one environment at a time)
     double lam0, lam1;                // running sums of lambda over the thread's loglambda slots: the NEXT step's S_t contributions
     double cv[BR_NCV];                // M pass: the thread's moment contributions
@@ -79,7 +80,7 @@ BB_DEV bb_d2 bs_draw_inline(unsigned long long seed, long long i0, unsigned step
 #endif
 // ... and the NEXT step's draw inside the same slot (the fused S part): 1 = inline, 0 = the out-of-line call
 #ifndef BS_S_INLINE_DRAW
-#define BS_S_INLINE_DRAW 0
+#define BS_S_INLINE_DRAW 1          /* (C5 63.9 -> 62.6 us) */
 #endif
 // BS_NT_HIST = 1: the window slot is read with the non-temporal policy (it is not touched again for a whole window; the state arrays,
 // re-read every step, keep the Infinity Cache): C5 90.8 -> 83.9 us (round 3)
@@ -123,8 +124,85 @@ template <int LPB> static inline double bs_emu_tree(const double* v) {          
 #define BS_GROUP_SUM(LPB, gv, tid, F) ([&]() { double v_[8]; for (int i_ = 0; i_ < (LPB); ++i_) v_[i_] = (gv)[((tid) & ~((LPB) - 1)) + i_].F; return bs_emu_tree<LPB>(v_); }())
 #endif
 
+// BS_LDESC = 1: the loglambda slots' pair descriptors by a form of their own (one replicate, compile-time T, the segment known: no search,
+// no division, i0 = lo + 2 q) instead of the general br_desc -- formed again in every pass, they were ~150 of a pair's ~1 700 VALU instructions
+#ifndef BS_LDESC
+#define BS_LDESC 1
+#endif
+// BS_ZKEEP = 1: a loglambda pair's sample z' stays in its LDS entry from the pass that formed it (the G pass of the step before) -- the M pass
+// takes its differences from there (the next pair's first sample: the neighbour entry, behind the barrier that ends the G passes), and the
+// G pass does NOT draw again: with z, mu and softplus(omega) at hand eps = (z - mu) / softplus(omega), which is what d z / d omega =
+// eps sigmoid(omega) needs.  One Philox4x32-10 + Box-Muller less per pair and step (205 VALU instructions, 20 of them quarter-rate 64-bit
+// multiplies, of ~1 200) in the pass that is bound by instruction issue.  The recovered eps is not the draw bit for bit: its relative
+// error is ulp(z) / |sigma eps| -- 1e-16 at the start of a run, 1e-13 .. 1e-12 for a converged loglambda (mu ~ 10, sigma ~ 1e-3) -- in ONE
+// term of d ELBO / d omega; the sample z, lambda = e^z and everything else are the S pass's own numbers.  0: the draw again, bit for bit.
+#ifndef BS_ZKEEP
+#define BS_ZKEEP 1
+#endif
+
 // number of pair slots that hold loglambda pairs (the loglambda segment comes first, at thread index 0), and its span
 BB_DEV int bs_lspan(const BRSeg* sg, int nseg) { return (nseg > 0 && sg[0].kind == SK_L) ? sg[0].tbeg + sg[0].span : 0; }
+
+// BS_PF0: between the M pass and the exchange -- the memory system idle until the G passes start -- the lines of the FIRST loglambda slot's
+// state are pulled towards the CU: 4 bytes per lane by LDS-DMA into a dump area (no register, nothing waits for them).  1 = the window
+// slot's lines (HBM: not touched for a whole window), 2 = all seven arrays.  (The same for the NEXT slot inside the G pass: measured
+// slower, 67.1 -> 68.8 / 72.6 us, profiles/r04b_stream_fused -- the pass is bound by the memory system itself.)
+#ifndef BS_PF0
+#define BS_PF0 0
+#endif
+template <int KIND, int TT>
+BB_DEV void bs_touch0(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, const BBSlot wslot) {
+#ifndef BB_EMU
+    if (!BS_PF0) return;
+    const BRSeg* sg = (const BRSeg*)(cx.lds + Y.seg);
+    const int nseg = ((const int*)(cx.lds + Y.L.misc))[0];
+    const int lspan = bs_lspan(sg, nseg), tid = threadIdx.x;
+    if (tid >= lspan) return;
+    const long long i0 = sg[0].lo + 2 * (long long)(tid - sg[0].tbeg), ih = i0 - sg[0].pad;
+    auto touch = [&](const void* p) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)((float*)(cx.lds + Y.eps) + (tid & ~63)), 4, 0, 0);
+    };
+    if (A.opt == 0) {
+        touch(S.hist + ((long long)wslot.slot * 2 + 0) * M.Dh + ih);
+        touch(S.hist + ((long long)wslot.slot * 2 + 1) * M.Dh + ih);
+    }
+    if (BS_PF0 > 1) { touch(S.mu + i0); touch(S.om + i0); touch(S.acc_mu + i0); touch(S.acc_om + i0); touch(S.accl + 2 * i0); }
+#else
+    (void)cx; (void)M; (void)S; (void)A; (void)Y; (void)wslot;
+#endif
+}
+
+// pair q of the tile's loglambda segment s0 (lane q = bl LPB + kk owns (b, 2 kk), (b, 2 kk + 1)): what br_desc's loglambda branch gives
+template <int KIND, int TT, bool CNT>
+BB_DEV void bs_desc_l(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int q, BRSt<1>& st, const double* lds) {
+    constexpr int LPB = TT / 2;
+    const int bl = q / LPB, kk = q - bl * LPB, t0 = 2 * kk;
+    const int E = KIND == 1 ? M.E : 1;
+    st.i0[0] = sg[0].lo + 2 * (long long)q;
+    int meta = SK_L | BRM_A0 | BRM_A1 | BRM_VALID | (kk > 0 ? BRM_PREV : 0) | (kk < LPB - 1 ? BRM_NEXT : 0);
+    st.pt[0] = t0;
+    st.uo[0][0] = st.uo[0][1] = st.uo[0][2] = 0;
+    st.thoff[0] = 0;
+    if (bl >= t.nshift) {
+        meta |= BRM_MUT;
+        const int ml = bl - t.nshift, base = ml * E;
+        if (KIND == 2) st.thoff[0] = ml - ((const int*)(lds + Y.gix))[ml];
+        if (E > 1) {
+            const int* envt = (const int*)(lds + Y.envt);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { const int tt = t0 - 1 + d; st.uo[0][d] = base + ((tt >= 0 && tt < TT - 1) ? envt[tt + 1] : 0); }
+        } else st.uo[0][0] = st.uo[0][1] = st.uo[0][2] = base;
+    }
+    st.meta[0] = meta;
+    if (CNT) {
+        const int co = ((const int*)(lds + Y.rtab))[3];
+        const long long cb = (co >= 0 ? (long long)co : M.cnt_off[0]) + t.b0 * TT + 2 * (long long)q;
+        st.cnt[0][0] = M.counts[cb];
+        st.cnt[0][1] = M.counts[cb + 1];
+    }
+}
+
 
 // ---- the sample of a pair: z = mu + softplus(omega) eps ------------------------------------------------------------------------------
 BB_DEV bb_d2 bs_z(const bb_d2 mu, const bb_d2 om, const bb_d2 e, bb_d2* sp, bb_d2* sg) {
@@ -140,7 +218,7 @@ BB_DEV bb_d2 bs_z(const bb_d2 mu, const bb_d2 om, const bb_d2 e, bb_d2* sp, bb_d
 BB_DEV void bs_put_l(double* lds, const BRLay& Y, int q, int meta, const bb_d2 z, double zn, BSG& g) {
     if (!(meta & BRM_VALID)) return;
     const bool hn = meta & BRM_NEXT;
-    *(bb_d2*)(lds + Y.zl + 2 * q) = bb_d2{z.y - z.x, hn ? zn - z.y : 0.0};
+    *(bb_d2*)(lds + Y.zl + 2 * q) = BS_ZKEEP ? z : bb_d2{z.y - z.x, hn ? zn - z.y : 0.0};
     g.lam0 += bb_exp(z.x);
     g.lam1 += bb_exp(z.y);
 }
@@ -229,12 +307,14 @@ BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             const int p = tid + k * cx.nthr;
             if (p >= lspan) break;          // (the loglambda segment comes first: later slots hold unit pairs only)
             BRSt<1>& st = g.st;
-            br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0, lds);
+            if (BS_LDESC) bs_desc_l<KIND, TT, false>(M, Y, t, sg, p - sg[0].tbeg, st, lds);
+            else br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0, lds);
             const int meta = st.meta[0];
             if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
             const bb_d2 d = *(const bb_d2*)(lds + Y.zl + 2 * (p - sg[0].tbeg));
             const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
             double dm = d.x, dn = d.y;
+            if (BS_ZKEEP) { dm = d.y - d.x; dn = hn ? lds[Y.zl + 2 * (p - sg[0].tbeg) + 2] - d.y : 0.0; }
             if (mut) {
                 double sm, sn, wm, wn;
                 br_unit_sw<KIND>(lds, Y, buf, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
@@ -290,10 +370,10 @@ BB_DEV void bs_load_state(const DevModel& M, const DevState& S, const double* hs
         { g.hm = br_load_pair<false>(hs_m, ih, a0, a1); g.ho = br_load_pair<false>(hs_o, ih, a0, a1); }
     }
 }
-// optimiser update of the pair from the likelihood + prior gradient (g0, g1) and the draw's a = eps sigmoid, h = sigmoid / softplus; stores
+// optimiser update of the pair from the likelihood + prior gradient (g0, g1) and the draw's a = eps sigmoid, h = sigmoid / softplus (g.a, g.h); stores
 BB_DEV bool bs_apply_store(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot wslot, double* hs_m, double* hs_o,
                            long long i0, long long ih, bool a0, bool a1, double g0, double g1, BSG& g) {
-    const double go0 = fma(g0, g.e.x * g.sg.x, g.sg.x * bb_rcp(g.sp.x)), go1 = fma(g1, g.e.y * g.sg.y, g.sg.y * bb_rcp(g.sp.y));
+    const double go0 = fma(g0, g.a.x, g.h.x), go1 = fma(g1, g.a.y, g.h.y);
     bb_d2 nhm = g.hm, nho = g.ho;
     if (a0) {
         bb_opt_apply(M, S, A, wslot, 0, ih, -g0, g.hm.x, &nhm.x, &g.mu.x, &g.am.x, &g.lo.x);
@@ -342,13 +422,26 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
             g.z = bb_d2{0.0, 0.0};
             g.xa = g.xq = g.rm = g.rn = 0.0;
             if (p < lspan) {
-                br_desc<KIND, 1, false, TT / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, g.st, 0, lds);
+                if (BS_LDESC) bs_desc_l<KIND, TT, true>(M, Y, t, sg, p - sg[0].tbeg, g.st, lds);
+                else br_desc<KIND, 1, false, TT / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, g.st, 0, lds);
                 if (g.st.meta[0] & BRM_VALID) {
                     g.ok = 1;
                     const long long i0 = g.st.i0[0];
                     bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[0].pad, true, true, g);
-                    g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
-                    g.z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);
+                    if (BS_ZKEEP) {
+                        g.z = *(const bb_d2*)(lds + Y.zl + 2 * (p - sg[0].tbeg));
+                        double sp0, sg0, sp1, sg1;
+                        bb_softplus_sigmoid(g.om.x, &sp0, &sg0);
+                        bb_softplus_sigmoid(g.om.y, &sp1, &sg1);
+                        const double r0 = bb_rcp(sp0), r1 = bb_rcp(sp1);
+                        g.a = bb_d2{(g.z.x - g.mu.x) * r0 * sg0, (g.z.y - g.mu.y) * r1 * sg1};          // eps = (z - mu) / softplus(omega)
+                        g.h = bb_d2{sg0 * r0, sg1 * r1};
+                    } else {
+                        g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
+                        g.z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);
+                        g.a = bb_d2{g.e.x * g.sg.x, g.e.y * g.sg.y};
+                        g.h = bb_d2{g.sg.x * bb_rcp(g.sp.x), g.sg.y * bb_rcp(g.sp.y)};
+                    }
                 }
             }
         }
@@ -382,6 +475,7 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 g.g1 = ((double)st.cnt[0][1] - l1) + l1 * lds[Y.iG + pt + 1] + rn_ - rm_ - (z1 - pm1) * iv1;
                 g.rm = mut ? rm : 0.0;
                 g.rn = mut ? rn : 0.0;
+                g.wm = wm;
             }
         }
         // C: the barcode's unit sums As = sum_t r, Qs = sum_t r^2 over the time steps that use the unit (multienv: per environment) --
@@ -402,6 +496,7 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 if (g.ok && (g.st.meta[0] & BRM_MUT) && ((p - sg[0].tbeg) & (LPB - 1)) == 0) {
                     const int u = g.st.uo[0][1] - (E > 1 ? g.st.uo[0][1] % E : 0) + e;          // stage index of unit (mutant, e)
                     *(bb_d2*)(aq + 2 * u) = bb_d2{As, Qs};
+                    if (KIND == 2) lds[Y.gas + u] = g.wm * As;          // d/ds_eff of the mutant: its genotype's theta sums these
                 }
             }
         }
@@ -423,11 +518,94 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
             if (g.ok) bs_put_l(lds, Y, p - sg[0].tbeg, g.st.meta[0], g.z, zn, g);
         }
     }
-    BB_STAMP(cx, S, 27);
-    BB_SYNC(cx);                     // the units' sums are in LDS
+    BB_STAMP(cx, S, 27);             // (no barrier here: the unit pass forms its first slot's sample before it meets the loglambda lanes)
 }
 
 // ---- G-U: the unit pair slots (and the replicated global latents on tile 0) ----------------------------------------------------------
+// part A of a slot: state in, the step's draw again, the owner's own sample -- nothing of it needs the loglambda lanes' sums
+template <int KIND, int TT>
+BB_DEV bool bs_unit_a(const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, const BBTile& t, const BRSeg* sg, int nseg, int g0t, int g1t,
+                      const double* hs_m, const double* hs_o, int p, int lspan, unsigned step, double* lds, BSG& g) {
+    g.ok = 0;
+    if (p < lspan) return false;
+    BRSt<1>& st = g.st;
+    br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
+    const int meta = st.meta[0];
+    if (!(meta & BRM_VALID)) return false;
+    const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+    const long long i0 = st.i0[0];
+    bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[meta >> 12].pad, a0, a1, g);
+    g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
+    g.z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);          // the owner's own sample of this step, again
+    g.a = bb_d2{g.e.x * g.sg.x, g.e.y * g.sg.y};
+    g.h = bb_d2{g.sg.x * bb_rcp(g.sp.x), g.sg.y * bb_rcp(g.sp.y)};
+    g.ok = 1;
+    return true;
+}
+// part B: gradient from the units' sums and the staged forms of THIS step, optimiser, everything out; the next step's sample, staged
+template <int KIND, int TT>
+BB_DEV bool bs_unit_b(const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, const BRSeg* sg, double* hs_m, double* hs_o,
+                      const BBSlot wslot, unsigned step, double* lds, BSG& g) {
+    const BBLds& L = Y.L;
+    const int buf = (int)(step & 1u), nbuf = buf ^ 1;
+    const int E = KIND == 1 ? M.E : 1;
+    const int* envt = (const int*)(lds + Y.envt);
+    const double* aq = lds + Y.hbuf;
+    const double* stg = lds + buf * Y.SU;
+    const BRSt<1>& st = g.st;
+    const int meta = st.meta[0], kind = meta & 15;
+    const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+    const long long i0 = st.i0[0], ih = i0 - sg[meta >> 12].pad;
+    double pm0, iv0, pm1, iv1, gl0 = 0.0, gl1 = 0.0;
+    br_pair_prior<KIND>(lds, Y, st, 0, a0, a1, &pm0, &iv0, &pm1, &iv1);
+    if (KIND == 2 && kind == SK_TH_R) {
+        // d/dtheta_g = sum over the genotype's mutants (consecutive units of this tile) of w As, left by their first loglambda lanes
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (!(x ? a1 : a0)) continue;
+            const int first = st.uo[0][x] & 0xffff, n = st.uo[0][x] >> 16;
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += lds[Y.gas + first + i];
+            (x ? gl1 : gl0) = s;
+        }
+    } else if (kind < SK_GS) {
+        // Per unit u = (mutant [, environment]) the sums over the time steps that use it, As = sum r, Qs = sum r^2 (the loglambda lanes
+        // left them), give d/ds_bc = w As, d/dlogsigma = w Qs - n; hierarchical: s_eff = theta + e^{logtau} theta_tilde, so
+        // d/dtheta_tilde = w As e^{logtau}, d/dlogtau = w As e^{logtau} theta_tilde
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (!(x ? a1 : a0)) continue;
+            const int j = st.zoff[0] + x;                      // stage index of the latent's unit
+            const bb_d2 AQ = *(const bb_d2*)(aq + 2 * j);
+            const double wv = stg[BR_ST(Y, KIND <= 1 ? 1 : 2) + j];
+            int nn = TT - 1;
+            if (E > 1) { const int e = (st.uo[0][2] >> (8 * x)) & 255; nn = 0; for (int tt = 0; tt < TT - 1; ++tt) nn += envt[tt + 1] == e ? 1 : 0; }
+            double acc;
+            if (KIND <= 1) acc = kind == SK_S ? wv * AQ.x : wv * AQ.y - (double)nn;
+            else if (kind == SK_LS_R) acc = wv * AQ.y - (double)nn;
+            else if (kind == SK_TT_R) acc = wv * AQ.x * stg[BR_ST(Y, 1) + j];                                          // e^{logtau}
+            else acc = wv * AQ.x * stg[BR_ST(Y, 1) + j] * stg[BR_ST(Y, 0) + j];                                        // logtau: e^{logtau} theta_tilde
+            (x ? gl1 : gl0) = acc;
+        }
+    } else {
+        const double* gg = lds + L.gglob + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
+        if (a0) gl0 = gg[0];
+        if (a1) gl1 = gg[1];
+    }
+    // (the replicated global latents' sample is rank 0's draw, back with the totals; on one GPU that is this thread's own)
+    double zv0 = g.z.x, zv1 = g.z.y;
+    if (kind >= SK_GS) {
+        const double* zz = lds + L.zgl + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
+        if (a0) zv0 = zz[0];
+        if (a1) zv1 = zz[1];
+    }
+    gl0 -= (zv0 - pm0) * iv0;
+    gl1 -= (zv1 - pm1) * iv1;
+    const bool bad = bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, ih, a0, a1, gl0, gl1, g);
+    const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
+    bs_put_u<KIND>(lds, M, Y, A, st, nbuf, bs_z(g.mu, g.om, en, &g.sp, &g.sg));
+    return bad;
+}
 template <int KIND, int TT>
 BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv) {
     double* lds = cx.lds;
@@ -436,92 +614,29 @@ BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const R
     const int g0t = KIND == 2 ? S.tile_g[cx.block] : 0, g1t = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
-    const int lspan = bs_lspan(sg, nseg), buf = (int)(step & 1u), nbuf = buf ^ 1;
-    const int E = KIND == 1 ? M.E : 1;
-    const int* envt = (const int*)(lds + Y.envt);
-    const double* aq = lds + Y.hbuf;
-    const double* stg = lds + buf * Y.SU;
+    const int lspan = bs_lspan(sg, nseg), k0 = lspan / cx.nthr;
     double* hs_m = nullptr;
     double* hs_o = nullptr;
     if (A.opt == 0) {
         hs_m = S.hist + ((long long)wslot.slot * 2 + 0) * M.Dh;
         hs_o = S.hist + ((long long)wslot.slot * 2 + 1) * M.Dh;
     }
-    // genotype model: pass 0 everything but theta (the theta_tilde thread of every mutant leaves w As in LDS), pass 1 theta
-    int th_lo = 0, th_hi = 0;
-    if (KIND == 2) for (int i = 0; i < nseg; ++i) if (sg[i].kind == SK_TH_R) { th_lo = sg[i].tbeg; th_hi = sg[i].tbeg + sg[i].span; }
-    for (int pass = 0; pass < (KIND == 2 ? 2 : 1); ++pass) {
-        if (pass) BB_SYNC(cx);
-        BB_PASS(cx, tid) {
-            BSG& g = BB_PSTATE(gv, tid);
-            bool bad = false;
-            for (int k = lspan / cx.nthr; k < P; ++k) {
-                const int p = tid + k * cx.nthr;
-                if (p < lspan) continue;
-                if (KIND == 2 && ((p >= th_lo && p < th_hi) != (pass == 1))) continue;      // (the theta segment's pairs: pass 1, everything else: pass 0)
-                BRSt<1>& st = g.st;
-                br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
-                const int meta = st.meta[0];
-                if (!(meta & BRM_VALID)) continue;
-                const int kind = meta & 15;
-                const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
-                const long long i0 = st.i0[0], ih = i0 - sg[meta >> 12].pad;
-                bs_load_state(M, S, hs_m, hs_o, i0, ih, a0, a1, g);
-                g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
-                const bb_d2 z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);          // the owner's own sample of this step, again
-                double pm0, iv0, pm1, iv1, gl0 = 0.0, gl1 = 0.0;
-                br_pair_prior<KIND>(lds, Y, st, 0, a0, a1, &pm0, &iv0, &pm1, &iv1);
-                if (KIND == 2 && kind == SK_TH_R) {
-#pragma unroll
-                    for (int x = 0; x < 2; ++x) {
-                        if (!(x ? a1 : a0)) continue;
-                        const int first = st.uo[0][x] & 0xffff, n = st.uo[0][x] >> 16;
-                        double s = 0.0;
-                        for (int i = 0; i < n; ++i) s += lds[Y.gas + first + i];
-                        (x ? gl1 : gl0) = s;
-                    }
-                } else if (kind < SK_GS) {
-                    // Per unit u = (mutant [, environment]) the sums over the time steps that use it, As = sum r, Qs = sum r^2 (the loglambda
-                    // lanes left them), give d/ds_bc = w As, d/dlogsigma = w Qs - n; hierarchical: s_eff = theta + e^{logtau} theta_tilde, so
-                    // d/dtheta_tilde = w As e^{logtau}, d/dlogtau = w As e^{logtau} theta_tilde, d/dtheta = sum over the genotype of w As
-#pragma unroll
-                    for (int x = 0; x < 2; ++x) {
-                        if (!(x ? a1 : a0)) continue;
-                        const int j = st.zoff[0] + x;                      // stage index of the latent's unit
-                        const bb_d2 AQ = *(const bb_d2*)(aq + 2 * j);
-                        const double wv = stg[BR_ST(Y, KIND <= 1 ? 1 : 2) + j];
-                        int nn = TT - 1;
-                        if (E > 1) { const int e = (st.uo[0][2] >> (8 * x)) & 255; nn = 0; for (int tt = 0; tt < TT - 1; ++tt) nn += envt[tt + 1] == e ? 1 : 0; }
-                        double acc;
-                        if (KIND <= 1) acc = kind == SK_S ? wv * AQ.x : wv * AQ.y - (double)nn;
-                        else if (kind == SK_LS_R) acc = wv * AQ.y - (double)nn;
-                        else if (kind == SK_TT_R) {
-                            acc = wv * AQ.x * stg[BR_ST(Y, 1) + j];                                          // e^{logtau}
-                            lds[Y.gas + j] = wv * AQ.x;                                                      // d/ds_eff: its genotype's theta sums these
-                        } else acc = wv * AQ.x * stg[BR_ST(Y, 1) + j] * stg[BR_ST(Y, 0) + j];                // logtau: e^{logtau} theta_tilde
-                        (x ? gl1 : gl0) = acc;
-                    }
-                } else {
-                    const double* gg = lds + L.gglob + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
-                    if (a0) gl0 = gg[0];
-                    if (a1) gl1 = gg[1];
-                }
-                // (the replicated global latents' sample is rank 0's draw, back with the totals; on one GPU that is this thread's own)
-                double zv0 = z.x, zv1 = z.y;
-                if (kind >= SK_GS) {
-                    const double* zz = lds + L.zgl + (kind == SK_GLS ? M.nt1 : 0) + st.zoff[0];
-                    if (a0) zv0 = zz[0];
-                    if (a1) zv1 = zz[1];
-                }
-                gl0 -= (zv0 - pm0) * iv0;
-                gl1 -= (zv1 - pm1) * iv1;
-                bad = bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, ih, a0, a1, gl0, gl1, g) || bad;
-                // the NEXT step's sample of the updated pair, staged for the other threads
-                const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
-                bs_put_u<KIND>(lds, M, Y, A, st, nbuf, bs_z(g.mu, g.om, en, &g.sp, &g.sg));
-            }
-            if (bad) *bad_any = 1;
-        }
+    // The first unit slot's part A runs BEFORE the barrier that makes the loglambda lanes' sums visible: most waves have no loglambda
+    // pair in the segment's last, partly filled slot and would only wait there for the one wave that has
+    BB_PASS(cx, tid) {
+        BSG& g = BB_PSTATE(gv, tid);
+        g.ok = 0;
+        if (k0 < P) bs_unit_a<KIND, TT>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k0 * cx.nthr, lspan, step, lds, g);
+    }
+    BB_SYNC(cx);                     // the units' sums (As, Qs; genotype model: w As) are in LDS
+    BB_PASS(cx, tid) {
+        BSG& g = BB_PSTATE(gv, tid);
+        bool bad = false;
+        if (g.ok) bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g);
+        for (int k = k0 + 1; k < P; ++k)
+            if (bs_unit_a<KIND, TT>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k * cx.nthr, lspan, step, lds, g))
+                bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g) || bad;
+        if (bad) *bad_any = 1;
     }
     BB_SYNC(cx);                     // the next step's tables are complete
     BB_STAMP(cx, S, 28);
@@ -555,6 +670,7 @@ __global__ void __launch_bounds__(NT) k_stream(const DevModel* __restrict__ Mp, 
             const unsigned long long step = step0 + (unsigned long long)done;
             const BBSlot wslot = bb_slot_now(A, sc);
             bs_moments<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, &g);
+            bs_touch0<KIND, TT>(cx, M, S, A, Y, wslot);
             br_row_publish<1, true, false>(cx, M, S, Y, nost, A.xepoch0 + (unsigned)(step + 1));
             br_xchg_lead<false>(cx, M, S, A, Y, step, ok_slot);
             br_xchg_consume<KIND, 1, false, false>(cx, M, S, A, Y, nost, step, ok_slot);

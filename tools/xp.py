@@ -25,7 +25,12 @@ import barbay_jl_amd as bb  # noqa: E402
 from barbay_jl_amd import _capi, synth  # noqa: E402
 
 WL = os.environ.get("WL", "fitness_normal")
-wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42) if WL == "fitness_normal" else getattr(synth, WL)()
+if WL == "fitness_normal":
+    wl = synth.fitness_normal(int(os.environ.get("B", 50000)), int(os.environ.get("T", 8)), 42)
+elif WL == "genotype_fitness_normal" and os.environ.get("B"):          # (B=25000 G=626: the shape one rank of C5's 8-GPU run holds, plain instance)
+    wl = synth.genotype_fitness_normal(int(os.environ["B"]), int(os.environ.get("T", 8)), int(os.environ.get("G", 626)), 45)
+else:
+    wl = getattr(synth, WL)()
 names = sys.argv[2:]
 PH = [(20, 21, "S"), (21, 23, "M"), (23, 24, "pub"), (24, 25, "X"), (25, 26, "F"), (26, 28, "G")]
 # k_stream since round 4 (one pass over the state per step: the next sample is formed inside the G passes): a step runs M -> G-U
