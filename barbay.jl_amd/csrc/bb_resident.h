@@ -158,7 +158,8 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     Y.ftab = o;    o += 2 * M.Ttot;
     Y.rtab = o;    o += 2 * M.R;          // [R] {tcum, zr0, T, cnt_off (or -1: beyond 31 bits, read from the model record)}
     Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
-    Y.gas = o;     o += M.kind == 2 ? Y.SU : 0;
+    o = (o + 1) & ~1;
+    Y.gas = o;     o += M.kind == 2 ? (stream ? Y.SU : 2 * Y.SU) : 0;      // (k_res: two terms per mutant as one 16-byte entry, br_theta_pre)
     Y.gix = o;     o += M.kind == 2 ? Y.SU + 1 : 0;
     Y.seg = o;     o += BR_SEG_DOUBLES * (4 + 4 * M.R + 1);      // (br_build_segs: at most R + 1 + 3 R + 2 segments, + the end marker)
     L.seg = Y.seg;
@@ -1078,6 +1079,44 @@ BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
         }
     }
 }
+// Genotype model, d/dtheta_g = sum over the genotype's mutants m of w_m As_m, As_m = sum_t r_t, r_t = (z_{t+1} - z_t) - s_eff - c_t:
+//   w As = w [(z_{T-1} - z_0) - (T - 1) s_eff]  -  w sum_t c_t
+// and only the c_t need the totals.  BR_TH_PRE = 1: every mutant's two terms w [..], w are formed IN THE EXCHANGE'S SHADOW (z rows and unit
+// forms are in LDS since barrier 1) and left in LDS; at the start of the G pass the theta thread adds its members' up, d/dtheta =
+// SA - SW sum_t c_t, and goes with all other pairs.  0 = round 3: the theta_tilde thread of every mutant leaves w As in LDS, one more
+// barrier, the theta threads add their members up and update in a second pass -- every wave waited for that chain at the next step's
+// barrier 1 (C5's rank shape, 25 000 x 8 / 626 genotypes: S 14.7 k cycles against C2's 10.0 k).
+#ifndef BR_TH_PRE
+#define BR_TH_PRE 1
+#endif
+template <int KIND, int P, int TT = 0>
+BB_DEV void br_theta_pre(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* stv, int buf) {
+    if (KIND != 2 || !BR_TH_PRE) return;
+    double* lds = cx.lds;
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if ((meta & 15) != SK_TT_R || !(meta & BRM_VALID)) continue;
+            // the theta_tilde thread of a mutant (idle here) leaves the mutant's two terms; its genotype's theta thread adds its members' up
+            // at the start of the G pass (a theta thread walking its ~40 members' rows itself, here, took 12 k cycles and held its tile's
+            // exchange up: profiles/r04c_theta_pre)
+            const int T = TT ? TT : M.T[0];
+            const double* zbuf = lds + Y.zl + buf * Y.NBT + Y.zr0[0];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                if (!(meta & (x ? BRM_A1 : BRM_A0))) continue;
+                const int j = st.zoff[k] + x, bl = st.uo[k][x], th = j - ((st.uo[k][2] >> (16 * x)) & 0xffff);
+                double sv, wv;
+                br_unit_sw<KIND>(lds, Y, buf, j, th, &sv, &wv);
+                const double* zr = zbuf + bl * (T + 1);
+                *(bb_d2*)(lds + Y.gas + 2 * j) = bb_d2{wv * ((zr[T - 1] - zr[0]) - (double)(T - 1) * sv), wv};
+            }
+        }
+    }
+}
+
 template <int KIND, int P, bool AP = false, bool PRE = (P == 1 && KIND <= 1)>
 BB_DEV void br_l_grad(const double* lds, const BRLay& Y, const BRSt<P>& st, int k, int buf, double* g0, double* g1) {
     const BBLds& L = Y.L;
@@ -1132,7 +1171,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     const double* zbuf = lds + Y.zl + buf * Y.NBT;
     // Genotype model: two passes.  Pass 0 updates everything but theta, and the theta_tilde thread of every mutant leaves w As in
     // LDS; after one more barrier the theta threads add up their genotypes' members (consecutive units of this tile) and update.
-    for (int pass = 0; pass < (KIND == 2 ? 2 : 1); ++pass) {
+    for (int pass = 0; pass < ((KIND == 2 && !BR_TH_PRE) ? 2 : 1); ++pass) {
     if (pass) BB_SYNC(cx);
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
@@ -1147,7 +1186,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
             const int meta = st.meta[k];
             if (!(meta & BRM_VALID)) continue;
             const int kind = meta & 15;
-            if (KIND == 2 && (kind == SK_TH_R) != (pass == 1)) continue;
+            if (KIND == 2 && !BR_TH_PRE && (kind == SK_TH_R) != (pass == 1)) continue;
             const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
             double pm0 = 0.0, pm1 = 0.0, iv0 = 0.0, iv1 = 0.0;       // (loglambda: the prior term is in st.gp already)
             if (kind != SK_L) br_pair_prior<KIND>(lds, Y, st, k, a0, a1, &pm0, &iv0, &pm1, &iv1);
@@ -1156,12 +1195,27 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                 br_l_grad<KIND, P, AP>(lds, Y, st, k, buf, &g0, &g1);
             } else if (KIND == 2 && kind == SK_TH_R) {
                 const double* stg = lds + buf * Y.SU;
+                double csum = 0.0;
+                if (BR_TH_PRE) { const int T = TT ? TT : M.T[0]; for (int tt = 0; tt < T - 1; ++tt) csum += lds[L.cc + tt]; }
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                     if (!(x ? a1 : a0)) continue;
-                    const int first = st.uo[k][x] & 0xffff, n = st.uo[k][x] >> 16;
                     double acc = 0.0;
-                    for (int i = 0; i < n; ++i) acc += lds[Y.gas + first + i];
+                    const int first = st.uo[k][x] & 0xffff, n = st.uo[k][x] >> 16;
+                    if (BR_TH_PRE) {          // (br_theta_pre: the members' terms w [..] and w, left in LDS before the exchange's barriers)
+                        // (four 16-byte entries in flight per round trip: one after the other the ~40 members of a genotype are 40 LDS
+                        //  round trips, 5 k cycles, that the whole tile waits for at the next barrier)
+                        const bb_d2* ge = (const bb_d2*)(lds + Y.gas) + first;
+                        double sa = 0.0, sw = 0.0;
+                        int i = 0;
+                        for (; i + 4 <= n; i += 4) {
+                            const bb_d2 e0 = ge[i], e1 = ge[i + 1], e2 = ge[i + 2], e3 = ge[i + 3];
+                            sa += (e0.x + e1.x) + (e2.x + e3.x);
+                            sw += (e0.y + e1.y) + (e2.y + e3.y);
+                        }
+                        for (; i < n; ++i) { sa += ge[i].x; sw += ge[i].y; }
+                        acc = sa - sw * csum;
+                    } else for (int i = 0; i < n; ++i) acc += lds[Y.gas + first + i];
                     (x ? g1 : g0) = acc;
                     (x ? z1 : z0) = stg[BR_ST(Y, 3) + st.zoff[k] + x];
                 }
@@ -1219,7 +1273,7 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                         else if (kind == SK_LS_R) acc = wv * Qs - (double)nn;
                         else if (kind == SK_TT_R) {
                             acc = wv * As * stg[BR_ST(Y, 1) + j];                                                // e^{logtau}
-                            if (KIND == 2) lds[Y.gas + j] = wv * As;                                         // d/ds_eff: its genotype's theta sums these
+                            if (KIND == 2 && !BR_TH_PRE) lds[Y.gas + j] = wv * As;                           // d/ds_eff: its genotype's theta sums these
                         }
                         else acc = wv * As * stg[BR_ST(Y, 1) + j] * stg[BR_ST(Y, 0) + j];                            // logtau: e^{logtau} theta_tilde
                     }
@@ -1312,6 +1366,7 @@ BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, con
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
     if (A.pf == 0 && prefetch) br_prefetch_slot<P, HD>(cx, M, S, A, Y, stv, slot);
     br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(xc & 1));          // what of this step's gradient needs no totals
+    br_theta_pre<KIND, P>(cx, M, Y, stv, (int)(xc & 1));          // (genotype model: the theta threads' sums over their members)
     br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, next_step, next_stream);         // the next normals, in the shadow of the rows' flight
 }
 template <bool XG>
