@@ -473,7 +473,6 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool 
     if (nthr > 512 && P == 1 && kind == 2) return T == 8 ? k_res<2, 1, 1024, false, 8> : k_res<2, 1, 1024, false>;
     return nullptr;
 #else
-    if (ms && xg) return nullptr;              // (several samples per step / ELBO recording: single-GPU instances only)
     switch (kind) {
     case 0: return bb_res_instance_k0(P, nthr, xg, T, ap, ms, nm);
     case 1: return bb_res_instance_k1(P, nthr, xg, T, ap, ms, nm);
@@ -491,6 +490,7 @@ static bb_stream_kernel stream_kernel(int kind, int nthr, int T, const char** nm
     if (nm) *nm = "(experiment build)";
     if (nthr == 1024 && kind == 0 && T == 8) return k_stream<0, 1024, 8>;
     if (nthr == 1024 && kind == 2 && T == 8) return k_stream<2, 1024, 8>;
+    if (nthr == 1024 && kind == 3 && T == 6) return k_stream<3, 1024, 6>;
     return nullptr;
 #else
     return bb_stream_instance(kind, nthr, T, nm);
@@ -671,17 +671,22 @@ static bool try_resident(bb_handle* h, bool any_parity) {
         if (h->p2p_on && nblk < 8) return false;
     }
     if (!h->p2p_on && h->M.Dh != h->M.Dp) return false;      // (packed window rows: only the cross-GPU instances read the segments' differences)
-    const int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
+    int P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr);
     // more pair slots than the register file holds: k_stream (bb_stream.h) -- the same tile map, the per-pair state streamed
     bool stream = false;
     const bool force_stream = (ev = getenv("BB_TUNE_STREAM")) && atoi(ev) > 0;        // (tests: small shapes through k_stream)
     if (force_stream || P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) {
-        const int T0 = h->M.T[0], lpb0 = br_lpb(T0);
+        const int T0 = uniform_T(h->M);
         const bool nostream = (ev = getenv("BB_NO_STREAM")) && atoi(ev) > 0;
-        stream = !nostream && h->M.R == 1 && h->M.kind <= 2 && !br_any_parity(h->M) && (T0 == 8 || T0 == 4) && 16 % lpb0 == 0 && h->nthr % 64 == 0 &&
-                 !h->p2p_on && h->o.samples_per_step == 1 && h->o.elbo_every == 0 && P <= 64;
+        // every replicate the same even T (instances: 4, 6, 8), flat-index-aligned pairs, one GPU, one sample per step, no ELBO trace
+        stream = !nostream && !br_any_parity(h->M) && (T0 == 8 || T0 == 6 || T0 == 4) && h->nthr % 64 == 0 &&
+                 !h->p2p_on && h->o.samples_per_step == 1 && h->o.elbo_every == 0;
+        if (stream) {          // (a barcode takes a power-of-two number of lanes there: T = 6 four)
+            P = (int)((br_tile_span(h->M, NB, true, true) + h->nthr - 1) / h->nthr);
+            if (P > 64) stream = false;
+        }
         if (!stream && !force_stream) return false;
-        if (!stream && P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false;
+        if (!stream) { P = (int)((br_tile_span(h->M, NB, true) + h->nthr - 1) / h->nthr); if (P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) return false; }
     }
     // When the window slot is fetched (RunArgs.pf).  In the exchange's shadow (round 2) its 32 B per latent of HBM reads compete with
     // the exchange's own loads and stores: at the start of the S pass instead, C2 73.1 -> 77.7 k steps/s, C4 87.1 -> 89.1 k
@@ -728,11 +733,11 @@ static int setup_persistent(bb_handle* h) {
     const char* ev = getenv("BB_NO_PERSIST");
     const bool want = h->o.launch_mode != 1 && !(ev && atoi(ev) > 0 && h->o.launch_mode == 0);
     const char* why = nullptr;
-    // several MC samples per step (Turing.ADVI(samples_per_step, ..), src/vi.jl:98) and ELBO recording: k_res's MS instances, on one GPU
+    // several MC samples per step (Turing.ADVI(samples_per_step, ..), src/vi.jl:98) and ELBO recording: k_res's MS instances (round 4: sharded too --
+    // every sample is an exchange of its own, the inbox epochs count exchanges)
     const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
     if (h->force_reduce || (h->o.world_size != 1 && !h->p2p_on)) why = "sharded run";
     else if (h->p2p_on && h->nblk < 8) why = "fewer than 8 tiles on this rank";   // (k_res's own tile map never has fewer tiles than this one)
-    else if (ms && h->p2p_on) why = h->o.samples_per_step != 1 ? "samples_per_step != 1 on a sharded run" : "ELBO recording is on (sharded run)";
     h->res_P = 0;
     const bool ap_first = ms || h->M.kind == BB_MODEL_GENOTYPE || (getenv("BB_TUNE_AP") && atoi(getenv("BB_TUNE_AP")) > 0);
     if (!why && want && try_resident(h, ap_first)) { h->persist_P = h->res_P; return 0; }
@@ -875,7 +880,8 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
             if (xg) br_xchg_lead<true>(cx, h->M, h->S, A, Y, xc, &E.ok);
             else br_xchg_lead<false>(cx, h->M, h->S, A, Y, xc, &E.ok);
         } else if (phase == 3) {
-            if (xg) br_xchg_consume<KIND, PP, true, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, false, 0, 0, wslot.slot);
+            if (xg && MSrun) br_xchg_consume<KIND, PP, true, true>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, want_el, ring, smp, last ? wslot.slot : -1);
+            else if (xg) br_xchg_consume<KIND, PP, true, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, false, 0, 0, wslot.slot);
             else if (MSrun) br_xchg_consume<KIND, PP, false, true>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, want_el, ring, smp, last ? wslot.slot : -1);
             else br_xchg_consume<KIND, PP, false, false>(cx, h->M, h->S, A, Y, sb, xc, &E.ok, false, 0, 0, wslot.slot);
             // (the compile-time-T forms of the G pass where the product has them, so that the emulation covers that code too)
@@ -903,7 +909,7 @@ static void emu_stream_phase(EmuPersist& E, int phase, long long it, long long n
         BSG* gb = gs + (size_t)b * h->nthr;
         int* bad_any = (int*)(cx.lds + Y.L.misc) + 3;
         if (phase == 0) {
-            br_tile_setup<KIND>(cx, h->M, h->S, A, Y, h->res_NB, h->nthr / 16);
+            br_tile_setup<KIND>(cx, h->M, h->S, A, Y, h->res_NB, KIND <= 2 ? h->nthr / 16 : h->nthr / 64);
             *bad_any = 0;
             bs_sample0<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)h->step, gb);      // (the launch's first sample; later ones: inside the G passes)
         } else if (phase == 1) {
@@ -925,10 +931,18 @@ static void emu_stream_phase(EmuPersist& E, int phase, long long it, long long n
 static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long long nsteps) {
     if (E.h->res_P && E.h->res_stream) {
         const int T = uniform_T(E.h->M);
+        auto byT = [&](auto kindc) {
+            constexpr int KIND = decltype(kindc)::value;
+            if (T == 8) emu_stream_phase<KIND, 8>(E, phase, it, nsteps);
+            else if (T == 6) emu_stream_phase<KIND, 6>(E, phase, it, nsteps);
+            else emu_stream_phase<KIND, 4>(E, phase, it, nsteps);
+        };
         switch (E.h->M.kind) {
-        case 0: T == 8 ? emu_stream_phase<0, 8>(E, phase, it, nsteps) : emu_stream_phase<0, 4>(E, phase, it, nsteps); break;
-        case 1: T == 8 ? emu_stream_phase<1, 8>(E, phase, it, nsteps) : emu_stream_phase<1, 4>(E, phase, it, nsteps); break;
-        default: T == 8 ? emu_stream_phase<2, 8>(E, phase, it, nsteps) : emu_stream_phase<2, 4>(E, phase, it, nsteps);
+        case 0: byT(std::integral_constant<int, 0>{}); break;
+        case 1: byT(std::integral_constant<int, 1>{}); break;
+        case 2: byT(std::integral_constant<int, 2>{}); break;
+        case 3: byT(std::integral_constant<int, 3>{}); break;
+        default: byT(std::integral_constant<int, 4>{});
         }
         return;
     }
@@ -2248,7 +2262,7 @@ extern "C" int bb_logdensity_grad(bb_handle* h, const double* z, double* logp, d
 
 extern "C" int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out) {
     if (!h || !out || n < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
-    BB_GROUP_UNSUPPORTED(h, "bb_get_elbo_trace");
+    if (!h->shards.empty()) return bb_get_elbo_trace(h->shards[0], first_step, n, out);      // (every shard forms the same estimate from the same totals)
     BB_ENTER(h);
     if (h->o.elbo_every <= 0) return bb_fail(BB_ERR_INVALID, "ELBO recording is off (elbo_every = 0)");
     std::vector<double> ring(BB_ELBO_RING);
@@ -2534,7 +2548,8 @@ static int hier_fitness_raw(bb_handle* h, int32_t n_samples, uint64_t seed, doub
     BB_ENTER(h);
     if (h->M.kind < BB_MODEL_GENOTYPE) return bb_fail(BB_ERR_INVALID, "bb_hier_fitness applies to the hierarchical models only");
     if (n_samples < 2 || n_samples > 16384) return bb_fail(BB_ERR_UNSUPPORTED, "n_samples must be in 2..16384");
-    if (h->o.world_size > 1) return bb_fail(BB_ERR_UNSUPPORTED, "bb_hier_fitness needs the whole posterior on one handle");
+    // (a shard of a sharded run keeps full-length parameter arrays but only its own barcodes' entries are current: the caller makes them
+    //  whole first -- bb_set_params with the gathered vector, as barbay.jl_amd.vi does -- the draws are then those of a whole-problem handle)
     const long long n = bb_hier_units(h);
     const size_t D = (size_t)h->M.D;
     int rc;

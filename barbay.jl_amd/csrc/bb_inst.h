@@ -12,12 +12,12 @@ typedef void (*bb_res_kernel)(const DevModel*, const DevState*, const BRLay*, Ru
 // (nm, where given: the selected instance as text, template arguments in declaration order -- bb_kernel_name)
 BB_INST bb_persist_kernel bb_persist_instance(int kind, int P, int nthr, bool xg, const char** nm = nullptr);
 // k_res<KIND, P, NT, XG, TT, AP, MS>: T = the model's common time-point count (0: replicates differ), compile-time in the BASELINE
-// shapes; ap = br_any_parity(model); ms = several MC samples per step and / or ELBO recording (single-GPU, generic-T instances)
+// shapes; ap = br_any_parity(model); ms = several MC samples per step and / or ELBO recording (generic-T instances; round 4: the cross-GPU ones too)
 BB_INST bb_res_kernel bb_res_instance_k0(int P, int nthr, bool xg, int T, bool ap, bool ms, const char** nm = nullptr);
 BB_INST bb_res_kernel bb_res_instance_k1(int P, int nthr, bool xg, int T, bool ap, bool ms, const char** nm = nullptr);
 BB_INST bb_res_kernel bb_res_instance_k2(int P, int nthr, bool xg, int T, bool ap, bool ms, const char** nm = nullptr);
 BB_INST bb_res_kernel bb_res_instance_k3(int P, int nthr, bool xg, int T, bool ap, bool ms, const char** nm = nullptr);
 BB_INST bb_res_kernel bb_res_instance_k4(int P, int nthr, bool xg, int T, bool ap, bool ms, const char** nm = nullptr);
-// k_stream<KIND, NT, TT>: kinds 0 .. 2, 1024 or 512 threads, T = 8 or 4
+// k_stream<KIND, NT, TT>: all five kinds, 1024 or 512 threads, T = 8, 6 or 4 (every replicate the same)
 BB_INST bb_stream_kernel bb_stream_instance(int kind, int nthr, int T, const char** nm = nullptr);
 #endif

@@ -3,9 +3,10 @@
 bb_stream_kernel bb_stream_instance(int kind, int nthr, int T, const char** nm) {
     if (nm) *nm = "";
 #define BS_CASE(K, NT, TT) if (kind == (K) && nthr == (NT) && T == (TT)) { if (nm) *nm = "k_stream<" #K "," #NT "," #TT ">"; return k_stream<K, NT, TT>; }
-    BS_CASE(0, 1024, 8) BS_CASE(1, 1024, 8) BS_CASE(2, 1024, 8)
+    BS_CASE(0, 1024, 8) BS_CASE(1, 1024, 8) BS_CASE(2, 1024, 8) BS_CASE(3, 1024, 8) BS_CASE(4, 1024, 8)
+    BS_CASE(0, 1024, 6) BS_CASE(1, 1024, 6) BS_CASE(2, 1024, 6) BS_CASE(3, 1024, 6) BS_CASE(4, 1024, 6)
     BS_CASE(0, 1024, 4) BS_CASE(1, 1024, 4) BS_CASE(2, 1024, 4)
-    BS_CASE(0, 512, 8) BS_CASE(1, 512, 8) BS_CASE(2, 512, 8)
+    BS_CASE(0, 512, 8) BS_CASE(1, 512, 8) BS_CASE(2, 512, 8) BS_CASE(3, 512, 6) BS_CASE(4, 512, 6)
 #undef BS_CASE
     return nullptr;
 }

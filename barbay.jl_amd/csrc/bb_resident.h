@@ -87,11 +87,14 @@ struct BRLay {
 // lanes per barcode of a loglambda segment: one per pair of time points.  (Any count works: the moment contributions are summed
 // by column walks over the segment's lanes, stride LPB, not by a butterfly over lane bits -- T = 6 used to idle one lane in four.)
 static inline int br_lpb(int T) { return (T + 1) / 2; }
+// k_stream (bb_stream.h): the lanes of a barcode exchange their samples and add their residuals up by DPP inside a 16-lane row, so a
+// barcode takes a power-of-two number of lanes (T = 6: four, the last one idle)
+BB_HD int br_lpb_stream(int T) { const int l = (T + 1) / 2; return l <= 1 ? 1 : (l <= 2 ? 2 : (l <= 4 ? 4 : 8)); }
 
 // padded thread-index span of a tile: loglambda segments wave-aligned, LPB lanes per barcode, then the unit pairs
-static inline long long br_tile_span(const DevModel& M, long long NB, bool globals) {
+static inline long long br_tile_span(const DevModel& M, long long NB, bool globals, bool stream = false) {
     long long p = 0;
-    for (int r = 0; r < M.R; ++r) p = ((p + 63) & ~63ll) + NB * br_lpb(M.T[r]);
+    for (int r = 0; r < M.R; ++r) p = ((p + 63) & ~63ll) + NB * (stream ? br_lpb_stream(M.T[r]) : br_lpb(M.T[r]));
     if (M.kind == 0 || M.kind == 1) p += 2 * (NB * M.E / 2 + 1);
     else if (M.kind == 2) p += 4 * (NB / 2 + 1);          // theta of the tile's own genotypes (at most NB), theta_tilde, logtau, logsigma
     else if (M.kind == 3) p += (NB / 2 + 1) + 3ll * M.R * (NB / 2 + 1);
@@ -113,6 +116,44 @@ static inline bool br_any_parity(const DevModel& M) {
     return false;
 }
 
+// The small tables of a tile -- everything whose size depends on the model's (K, nt1, Ttot, R) only -- come FIRST in LDS, in this order
+// (round 4).  (Measured and dropped: telling the compiler these offsets and the model constants behind them as compile-time constants in
+// the instances whose time-point count is a template argument -- __builtin_assume on every field, to take ~20 uniform values out of a
+// step loop that holds more of them than there are SGPRs: the spill count did not move, 296 -> 300 v_readlane_b32, C2 11.87 -> 11.95 us,
+// C4 unchanged; profiles/r04d_c2_experiments.)
+struct BRHdr { int rowmap, tmap, wk, zgl, Lt, invS, cc, wbar, gglob, misc, part, Dt, elbt, iG, csum, ftab, rtab, envt, seg, end; };
+#ifndef BB_EMU
+__host__ __device__
+#endif
+inline constexpr BRHdr br_header(int K, int nt1, int Ttot, int R) {
+    BRHdr h{};
+    const int KK = K + 2 * nt1;
+    int o = 0;
+    h.rowmap = o;  o += K + 1;                // [K] int pairs
+    h.tmap = o;    o += (K + 1) / 2 + 1;
+    h.wk = o;      o += KK;
+    h.zgl = o;     o += 2 * nt1;
+    h.Lt = o;      o += Ttot;
+    h.invS = o;    o += Ttot;
+    h.cc = o;      o += Ttot + 1;
+    h.wbar = o;    o += Ttot + 1;
+    h.gglob = o;   o += 2 * nt1;
+    h.misc = o;    o += 16 + BB_MAX_REP;
+    h.part = o;    o += 32;
+    h.Dt = o;      o += Ttot + 1;
+    h.elbt = o;    o += Ttot;
+    h.iG = o;      o += Ttot;
+    h.csum = o;    o += BB_MAX_REP;
+    o = (o + 1) & ~1;
+    h.ftab = o;    o += 2 * Ttot;
+    h.rtab = o;    o += 2 * R;                // [R] {tcum, zr0, T, cnt_off (or -1: beyond 31 bits, read from the model record)}
+    h.envt = o;    o += (Ttot + 1) / 2 + 1;
+    o = (o + 1) & ~1;
+    h.seg = o;     o += BR_SEG_DOUBLES * (4 + 4 * R + 1);      // (br_build_segs: at most R + 1 + 3 R + 2 segments, + the end marker)
+    h.end = (o + 1) & ~1;
+    return h;
+}
+
 static inline
 #ifndef BB_EMU
 __host__ __device__
@@ -123,14 +164,22 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     const int KK = M.K + 2 * M.nt1;
     int o = 0;
     int lmax = 1;
-    for (int r = 0; r < BB_MAX_REP; ++r) { Y.lpb[r] = r < M.R ? br_lpb(M.T[r]) : 1; if (Y.lpb[r] > lmax) lmax = Y.lpb[r]; }
+    for (int r = 0; r < BB_MAX_REP; ++r) { Y.lpb[r] = r < M.R ? (stream ? br_lpb_stream(M.T[r]) : br_lpb(M.T[r])) : 1; if (Y.lpb[r] > lmax) lmax = Y.lpb[r]; }
     BBLds& L = Y.L;
     L = BBLds{};
     Y.NBT = 0;
     for (int r = 0; r < BB_MAX_REP; ++r) { Y.zr0[r] = Y.NBT; if (r < M.R) Y.NBT += NB * (M.T[r] + 1); }
     Y.NBT = (Y.NBT + 1) & ~1;
-    // (k_stream, bb_stream.h: no z rows at all -- the region holds a loglambda pair's two forward differences, one private 16-byte entry per
-    //  pair, [NB][T] doubles at most; its unit stage tables are double-buffered like k_res's, but only the forms OTHER threads read are staged)
+    // (k_stream, bb_stream.h: no z rows at all -- the region holds the loglambda pairs' samples, one 16-byte entry per pair, [R][NB][T / 2];
+    //  its unit stage tables are double-buffered like k_res's, but only the forms OTHER threads read are staged)
+    if (stream) { long long sp = 0; for (int r = 0; r < M.R; ++r) sp += (long long)NB * (M.T[r] / 2); Y.NBT = (int)(2 * sp + 2); }      // ([R][NB][T / 2] pairs)
+    {
+        const BRHdr H = br_header(M.K, M.nt1, M.Ttot, M.R);
+        Y.rowmap = H.rowmap; L.tmap = H.tmap; L.wk = H.wk; L.zgl = H.zgl; L.Lt = H.Lt; L.invS = H.invS; L.cc = H.cc; L.GG = H.wbar; L.wbar = H.wbar;
+        L.gglob = H.gglob; L.misc = H.misc; L.part = H.part; L.Dt = H.Dt; L.elbt = H.elbt; Y.iG = H.iG; Y.csum = H.csum; Y.ftab = H.ftab;
+        Y.rtab = H.rtab; Y.envt = H.envt; Y.seg = H.seg; L.seg = H.seg;
+        o = H.end;
+    }
     Y.zlw = stream ? 1 : 2;
     Y.zl = o;      o += Y.zlw * Y.NBT;
     Y.SU = NB * X;
@@ -138,31 +187,9 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     Y.stw = 2 * Y.SU;
     for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += Y.stw; }
     o = (o + 1) & ~1;
-    Y.rowmap = o;  o += M.K + 1;          // [K] int pairs
-    L.tmap = o;    o += (M.K + 1) / 2 + 1;
-    L.wk = o;      o += KK;
-    L.zgl = o;     o += 2 * M.nt1;
-    L.Lt = o;      o += M.Ttot;
-    L.invS = o;    o += M.Ttot;
-    L.cc = o;      o += M.Ttot + 1;
-    L.GG = o;
-    L.wbar = o;    o += M.Ttot + 1;
-    L.gglob = o;   o += 2 * M.nt1;
-    L.misc = o;    o += 16 + BB_MAX_REP;
-    L.part = o;    o += 32;
-    L.Dt = o;      o += M.Ttot + 1;
-    L.elbt = o;    o += M.Ttot;
-    Y.iG = o;      o += M.Ttot;
-    Y.csum = o;    o += BB_MAX_REP;
-    o = (o + 1) & ~1;
-    Y.ftab = o;    o += 2 * M.Ttot;
-    Y.rtab = o;    o += 2 * M.R;          // [R] {tcum, zr0, T, cnt_off (or -1: beyond 31 bits, read from the model record)}
-    Y.envt = o;    o += (M.Ttot + 1) / 2 + 1;
-    o = (o + 1) & ~1;
-    Y.gas = o;     o += M.kind == 2 ? (stream ? Y.SU : 2 * Y.SU) : 0;      // (k_res: two terms per mutant as one 16-byte entry, br_theta_pre)
+    // (k_res: two terms per mutant as one 16-byte entry, br_theta_pre; k_stream: w As of every unit of the hierarchical kinds, bs_update_l)
+    Y.gas = o;     o += stream ? (M.kind >= 2 ? Y.SU : 0) : (M.kind == 2 ? 2 * Y.SU : 0);
     Y.gix = o;     o += M.kind == 2 ? Y.SU + 1 : 0;
-    Y.seg = o;     o += BR_SEG_DOUBLES * (4 + 4 * M.R + 1);      // (br_build_segs: at most R + 1 + 3 R + 2 segments, + the end marker)
-    L.seg = Y.seg;
     o = (o + 1) & ~1;
     // One transient region, users that never overlap in time: the transposed moment contributions (M pass -> row sums), then --
     // from the publish of the tile's row to the next step's S / G passes -- the drawn-ahead normals and the prefetched window slot.
@@ -173,7 +200,9 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
         Y.racc_r[r] = Y.racc + racc_total;
         // (k_stream: a thread adds its pair slots' contributions up in registers, the 16-lane rows of a wave reduce them by class, so a
         //  column holds one entry per (row of 16 lanes, class) instead of one per lane of the segment)
-        Y.rw[r] = r < M.R ? (stream ? (NT / 16) * Y.lpb[r] : (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll)) : 0;
+        // (several replicates, round 4: LDS is short there -- the four rows of a wave add up as well, one entry per (wave, class); the two lane
+        //  exchanges per value that costs took C5's M pass from 7.6 k to 12.6 k cycles, so one replicate keeps the entry per row)
+        Y.rw[r] = r < M.R ? (stream ? (NT / (M.R == 1 ? 16 : 64)) * Y.lpb[r] : (int)(((long long)NB * Y.lpb[r] + 63) & ~63ll)) : 0;
         if (r < M.R) racc_total += BR_NCV * (Y.rw[r] + 4);
     }
     // Staging of the cross-GPU inbox rows (bbp_consume<true>; xg_rows = 8 x world rows of KK entries, summed in chunks of whole rows):

@@ -36,9 +36,9 @@
 // ELSE reads are staged (an owner recomputes its own sample with its draw): fitness / multienv 2 tables (s, w), hierarchical 4
 // (theta_tilde, e^logtau, w, theta) -- C5's tile: 141 -> 154 KB.  The launch starts with the first step's sample alone (bs_sample0).
 //
-// Shapes: one replicate (fitness, multienv, genotype kinds), an even number of time points whose lanes per barcode divide 16
-// (T = 2, 4, 8, 16; instances for the BASELINE shapes' T = 8 and for 4), flat-index-aligned pairs (no AP), one GPU, one MC sample per
-// step, no ELBO recording.  Everything else keeps its launch.
+// Shapes: all five model kinds, every replicate with the same EVEN number of time points (instances: T = 4, 6, 8 -- a barcode takes a
+// power-of-two number of lanes, T = 6: four with the last one idle, so that its lanes sit inside one 16-lane row), flat-index-aligned
+// pairs (no AP), not the ragged-method pairing, one GPU, one MC sample per step, no ELBO recording.  Everything else keeps its launch.
 #pragma once
 #include "bb_resident.h"
 
@@ -124,11 +124,6 @@ template <int LPB> static inline double bs_emu_tree(const double* v) {          
 #define BS_GROUP_SUM(LPB, gv, tid, F) ([&]() { double v_[8]; for (int i_ = 0; i_ < (LPB); ++i_) v_[i_] = (gv)[((tid) & ~((LPB) - 1)) + i_].F; return bs_emu_tree<LPB>(v_); }())
 #endif
 
-// BS_LDESC = 1: the loglambda slots' pair descriptors by a form of their own (one replicate, compile-time T, the segment known: no search,
-// no division, i0 = lo + 2 q) instead of the general br_desc -- formed again in every pass, they were ~150 of a pair's ~1 700 VALU instructions
-#ifndef BS_LDESC
-#define BS_LDESC 1
-#endif
 // BS_ZKEEP = 1: a loglambda pair's sample z' stays in its LDS entry from the pass that formed it (the G pass of the step before) -- the M pass
 // takes its differences from there (the next pair's first sample: the neighbour entry, behind the barrier that ends the G passes), and the
 // G pass does NOT draw again: with z, mu and softplus(omega) at hand eps = (z - mu) / softplus(omega), which is what d z / d omega =
@@ -140,8 +135,15 @@ template <int LPB> static inline double bs_emu_tree(const double* v) {          
 #define BS_ZKEEP 1
 #endif
 
-// number of pair slots that hold loglambda pairs (the loglambda segment comes first, at thread index 0), and its span
-BB_DEV int bs_lspan(const BRSeg* sg, int nseg) { return (nseg > 0 && sg[0].kind == SK_L) ? sg[0].tbeg + sg[0].span : 0; }
+// lanes per barcode (br_lpb_stream, as a constant)
+template <int TT> BB_DEV constexpr int bs_lpb() { return TT <= 2 ? 1 : (TT <= 4 ? 2 : (TT <= 8 ? 4 : 8)); }
+// end of the loglambda segments in the tile's padded thread-index space (one segment per replicate, each starting at a wave boundary;
+// they come first): slots below it hold loglambda pairs or padding, slots from it on unit pairs
+BB_DEV int bs_lspan(const BRSeg* sg, int nseg) {
+    int e = 0;
+    for (int i = 0; i < nseg && sg[i].kind == SK_L; ++i) e = sg[i].tbeg + sg[i].span;
+    return e;
+}
 
 // BS_PF0: between the M pass and the exchange -- the memory system idle until the G passes start -- the lines of the FIRST loglambda slot's
 // state are pulled towards the CU: 4 bytes per lane by LDS-DMA into a dump area (no register, nothing waits for them).  1 = the window
@@ -157,7 +159,7 @@ BB_DEV void bs_touch0(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     const BRSeg* sg = (const BRSeg*)(cx.lds + Y.seg);
     const int nseg = ((const int*)(cx.lds + Y.L.misc))[0];
     const int lspan = bs_lspan(sg, nseg), tid = threadIdx.x;
-    if (tid >= lspan) return;
+    if (tid >= lspan || tid >= sg[0].tbeg + sg[0].span || TT != 2 * bs_lpb<TT>()) return;
     const long long i0 = sg[0].lo + 2 * (long long)(tid - sg[0].tbeg), ih = i0 - sg[0].pad;
     auto touch = [&](const void* p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
@@ -173,36 +175,43 @@ BB_DEV void bs_touch0(BBCtx& cx, const DevModel& M, const DevState& S, const Run
 #endif
 }
 
-// pair q of the tile's loglambda segment s0 (lane q = bl LPB + kk owns (b, 2 kk), (b, 2 kk + 1)): what br_desc's loglambda branch gives
+// pair slot p of the tile's loglambda segments (lane q = bl LPB + kk of replicate r's segment owns (b, 2 kk), (b, 2 kk + 1) of that
+// replicate): what br_desc's loglambda branch gives, without the search through all segments, with the lanes per barcode a constant
 template <int KIND, int TT, bool CNT>
-BB_DEV void bs_desc_l(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int q, BRSt<1>& st, const double* lds) {
-    constexpr int LPB = TT / 2;
-    const int bl = q / LPB, kk = q - bl * LPB, t0 = 2 * kk;
-    const int E = KIND == 1 ? M.E : 1;
-    st.i0[0] = sg[0].lo + 2 * (long long)q;
-    int meta = SK_L | BRM_A0 | BRM_A1 | BRM_VALID | (kk > 0 ? BRM_PREV : 0) | (kk < LPB - 1 ? BRM_NEXT : 0);
-    st.pt[0] = t0;
+BB_DEV void bs_desc_l(const DevModel& M, const BRLay& Y, const BBTile& t, const BRSeg* sg, int p, BRSt<1>& st, const double* lds) {
+    constexpr int LPB = bs_lpb<TT>();
+    const int R = KIND <= 2 ? 1 : M.R;
+    int r = 0;
+    if (KIND >= 3) { while (r + 1 < R && p >= sg[r + 1].tbeg) ++r; }
+    const int q = p - sg[r].tbeg, bl = q / LPB, kk = q - bl * LPB, t0 = 2 * kk;
+    const int E = (KIND == 1 || KIND == 4) ? M.E : 1;
+    st.meta[0] = 15;
     st.uo[0][0] = st.uo[0][1] = st.uo[0][2] = 0;
     st.thoff[0] = 0;
+    if (q >= sg[r].span || t0 >= TT) return;          // (padding behind the segment; T = 6: a barcode's fourth lane)
+    const int* rtb = (const int*)(lds + Y.rtab) + 4 * r;          // {tcum, -, T, first count}
+    st.i0[0] = sg[r].lo + (long long)bl * TT + t0;
+    st.zoff[0] = 2 * ((r * t.NB + bl) * (TT / 2) + kk);          // the pair's 16-byte entry in the sample table: [R][NB][T / 2] pairs
+    int meta = SK_L | BRM_A0 | BRM_A1 | BRM_VALID | (kk > 0 ? BRM_PREV : 0) | (t0 + 2 < TT ? BRM_NEXT : 0) | (r << 12);
+    st.pt[0] = rtb[0] + t0;
     if (bl >= t.nshift) {
         meta |= BRM_MUT;
-        const int ml = bl - t.nshift, base = ml * E;
-        if (KIND == 2) st.thoff[0] = ml - ((const int*)(lds + Y.gix))[ml];
+        const int ml = bl - t.nshift, base = (KIND >= 3 ? r * t.NB + ml : ml) * E;
+        st.thoff[0] = KIND >= 3 ? r * t.NB * E : (KIND == 2 ? ml - ((const int*)(lds + Y.gix))[ml] : 0);
         if (E > 1) {
             const int* envt = (const int*)(lds + Y.envt);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { const int tt = t0 - 1 + d; st.uo[0][d] = base + ((tt >= 0 && tt < TT - 1) ? envt[tt + 1] : 0); }
+            for (int d = 0; d < 3; ++d) { const int tt = t0 - 1 + d; st.uo[0][d] = base + ((tt >= 0 && tt < TT - 1) ? envt[rtb[0] + tt + 1] : 0); }
         } else st.uo[0][0] = st.uo[0][1] = st.uo[0][2] = base;
     }
     st.meta[0] = meta;
     if (CNT) {
-        const int co = ((const int*)(lds + Y.rtab))[3];
-        const long long cb = (co >= 0 ? (long long)co : M.cnt_off[0]) + t.b0 * TT + 2 * (long long)q;
+        const int co = rtb[3];
+        const long long cb = (co >= 0 ? (long long)co : M.cnt_off[r]) + (t.b0 + bl) * TT + t0;
         st.cnt[0][0] = M.counts[cb];
         st.cnt[0][1] = M.counts[cb + 1];
     }
 }
-
 
 // ---- the sample of a pair: z = mu + softplus(omega) eps ------------------------------------------------------------------------------
 BB_DEV bb_d2 bs_z(const bb_d2 mu, const bb_d2 om, const bb_d2 e, bb_d2* sp, bb_d2* sg) {
@@ -215,12 +224,13 @@ BB_DEV bb_d2 bs_z(const bb_d2 mu, const bb_d2 om, const bb_d2 e, bb_d2* sp, bb_d
 }
 // what a loglambda pair leaves for the NEXT step's M pass: its two forward differences in the thread's private LDS entry, lambda on the
 // thread's running sums (zn: the next pair's first sample, by DPP)
-BB_DEV void bs_put_l(double* lds, const BRLay& Y, int q, int meta, const bb_d2 z, double zn, BSG& g) {
+template <int KIND>
+BB_DEV void bs_put_l(double* lds, const BRLay& Y, int zoff, int meta, const bb_d2 z, double zn, BSG& g) {
     if (!(meta & BRM_VALID)) return;
     const bool hn = meta & BRM_NEXT;
-    *(bb_d2*)(lds + Y.zl + 2 * q) = BS_ZKEEP ? z : bb_d2{z.y - z.x, hn ? zn - z.y : 0.0};
-    g.lam0 += bb_exp(z.x);
-    g.lam1 += bb_exp(z.y);
+    *(bb_d2*)(lds + Y.zl + zoff) = BS_ZKEEP ? z : bb_d2{z.y - z.x, hn ? zn - z.y : 0.0};
+    // (one replicate: a thread's pairs share their S_t rows, lambda joins running sums; several: the M pass takes e^z again, per replicate)
+    if (KIND <= 2) { g.lam0 += bb_exp(z.x); g.lam1 += bb_exp(z.y); }
 }
 // ... and a unit pair: the forms OTHER threads read, into the stage tables of buffer `buf` (an owner recomputes its own sample)
 template <int KIND>
@@ -264,7 +274,8 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     for (int k = 0; k < P; ++k) {
         BB_PASS(cx, tid) {
             BSG& g = BB_PSTATE(gv, tid);
-            br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, g.st, 0, lds);
+            if (tid + k * cx.nthr < lspan) bs_desc_l<KIND, TT, false>(M, Y, t, sg, tid + k * cx.nthr, g.st, lds);
+            else br_desc<KIND, 1, false, bs_lpb<TT>(), false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, g.st, 0, lds);
             const int meta = g.st.meta[0];
             g.z = bb_d2{0.0, 0.0};
             if (meta & BRM_VALID) {
@@ -277,7 +288,7 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             BSG& g = BB_PSTATE(gv, tid);
             const double zn = BS_NEXT(gv, tid, z.x);
             const int p = tid + k * cx.nthr, meta = g.st.meta[0];
-            if (p < lspan) bs_put_l(lds, Y, p - sg[0].tbeg, meta, g.z, zn, g);
+            if (p < lspan) { if ((meta & 15) == SK_L) bs_put_l<KIND>(lds, Y, g.st.zoff[0], meta, g.z, zn, g); }
             else bs_put_u<KIND>(lds, M, Y, A, g.st, (int)(step & 1u), g.z);
         }
     }
@@ -285,71 +296,81 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     BB_STAMP(cx, S, 21);
 }
 
-// ---- M: the loglambda pairs' moment contributions, summed per thread, then by class over the wave's rows, one LDS entry each ----
+// ---- M: the loglambda pairs' moment contributions, summed per thread, then by class over the wave, one LDS entry per (wave, class, value) ----
 template <int KIND, int TT>
 BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
-    const int g0 = KIND == 2 ? S.tile_g[cx.block] : 0, g1 = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
-    constexpr int LPB = TT / 2;
-    const int stride = Y.rw[0] + 4, buf = (int)(step & 1u), lspan = bs_lspan(sg, nseg);
+    constexpr int LPB = bs_lpb<TT>();
+    const int buf = (int)(step & 1u), lspan = bs_lspan(sg, nseg);
+    const int R = KIND <= 2 ? 1 : M.R;
     BB_STAMP(cx, S, 22);
-    BB_PASS(cx, tid) {
-        BSG& g = BB_PSTATE(gv, tid);
+    // (several replicates: a thread's slots may sit in different replicates' segments -- one round per replicate; the DPP sums need whole
+    //  waves, so every thread takes every round)
+    for (int r = 0; r < R; ++r) {
+        const int stride = Y.rw[r] + 4;
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
 #pragma unroll
-        for (int q = 0; q < BR_NCV; ++q) g.cv[q] = 0.0;
-        g.cv[0] = g.lam0; g.cv[6] = g.lam1;          // (summed while the pairs were sampled)
-        g.lam0 = g.lam1 = 0.0;
-        for (int k = 0; k < P; ++k) {
-            const int p = tid + k * cx.nthr;
-            if (p >= lspan) break;          // (the loglambda segment comes first: later slots hold unit pairs only)
-            BRSt<1>& st = g.st;
-            if (BS_LDESC) bs_desc_l<KIND, TT, false>(M, Y, t, sg, p - sg[0].tbeg, st, lds);
-            else br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0, g1, p, st, 0, lds);
-            const int meta = st.meta[0];
-            if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
-            const bb_d2 d = *(const bb_d2*)(lds + Y.zl + 2 * (p - sg[0].tbeg));
-            const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
-            double dm = d.x, dn = d.y;
-            if (BS_ZKEEP) { dm = d.y - d.x; dn = hn ? lds[Y.zl + 2 * (p - sg[0].tbeg) + 2] - d.y : 0.0; }
-            if (mut) {
-                double sm, sn, wm, wn;
-                br_unit_sw<KIND>(lds, Y, buf, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
-                if (KIND == 1) br_unit_sw<KIND>(lds, Y, buf, st.uo[0][2], 0, &sn, &wn);
-                else { sn = sm; wn = wm; }
-                dm -= sm; dn -= sn;
-                g.cv[1] += wm; g.cv[2] += wm * dm; g.cv[3] += wm * dm * dm;
-                if (hn) { g.cv[7] += wn; g.cv[8] += wn * dn; g.cv[9] += wn * dn * dn; }
-            } else {
-                g.cv[4] += dm; g.cv[5] += dm * dm;
-                if (hn) { g.cv[10] += dn; g.cv[11] += dn * dn; }
+            for (int q = 0; q < BR_NCV; ++q) g.cv[q] = 0.0;
+            if (KIND <= 2) { g.cv[0] = g.lam0; g.cv[6] = g.lam1; g.lam0 = g.lam1 = 0.0; }          // (summed while the pairs were sampled)
+            const int lo = (nseg > r && sg[r].kind == SK_L) ? sg[r].tbeg : 0, hi = (nseg > r && sg[r].kind == SK_L) ? sg[r].tbeg + sg[r].span : 0;
+            for (int k = 0; k < P; ++k) {
+                const int p = tid + k * cx.nthr;
+                if (p >= hi) break;
+                if (p < lo) continue;
+                BRSt<1>& st = g.st;
+                bs_desc_l<KIND, TT, false>(M, Y, t, sg, p, st, lds);
+                const int meta = st.meta[0];
+                if ((meta & 15) != SK_L || !(meta & BRM_VALID)) continue;
+                const bb_d2 d = *(const bb_d2*)(lds + Y.zl + st.zoff[0]);
+                const bool hn = meta & BRM_NEXT, mut = meta & BRM_MUT;
+                double dm = d.x, dn = d.y;
+                if (BS_ZKEEP) { dm = d.y - d.x; dn = hn ? lds[Y.zl + st.zoff[0] + 2] - d.y : 0.0; }
+                if (KIND >= 3) { g.cv[0] += bb_exp(d.x); g.cv[6] += bb_exp(d.y); }
+                if (mut) {
+                    double sm, sn, wm, wn;
+                    br_unit_sw<KIND>(lds, Y, buf, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
+                    if (KIND == 1 || KIND == 4) br_unit_sw<KIND>(lds, Y, buf, st.uo[0][2], KIND >= 3 ? st.thoff[0] : 0, &sn, &wn);
+                    else { sn = sm; wn = wm; }
+                    dm -= sm; dn -= sn;
+                    g.cv[1] += wm; g.cv[2] += wm * dm; g.cv[3] += wm * dm * dm;
+                    if (hn) { g.cv[7] += wn; g.cv[8] += wn * dn; g.cv[9] += wn * dn * dn; }
+                } else {
+                    g.cv[4] += dm; g.cv[5] += dm * dm;
+                    if (hn) { g.cv[10] += dn; g.cv[11] += dn * dn; }
+                }
             }
-        }
 #ifndef BB_EMU
-        // a thread's pairs share their class (tid % LPB): lanes of equal class in a 16-lane row add up, the row's first LPB lanes store
-        const int lane16 = tid & 15, row = tid >> 4;
+            // a thread's pairs share their class (tid % LPB): lanes of equal class add up over the 16-lane row (DPP), the wave's four rows
+            // over two lane exchanges; the wave's first LPB lanes store
+            // (several replicates: the wave's four rows add up too, over two lane exchanges -- LDS is short there, see br_layout)
+            const int lane = KIND <= 2 ? (tid & 15) : (tid & 63), grp = KIND <= 2 ? (tid >> 4) : (tid >> 6);
 #pragma unroll
-        for (int q = 0; q < BR_NCV; ++q) {
-            const double v = bs_class_sum<LPB>(g.cv[q]);
-            if (lane16 < LPB) lds[Y.racc_r[0] + q * stride + row * LPB + lane16] = v;
-        }
-#endif
-    }
-#ifdef BB_EMU
-    BB_PASS(cx, tid) {      // (the emulation adds a row's lanes of one class in lane order)
-        const int lane16 = tid & 15, row = tid >> 4;
-        if (lane16 < LPB) {
             for (int q = 0; q < BR_NCV; ++q) {
-                double v = 0.0;
-                for (int i = lane16; i < 16; i += LPB) v += BB_PSTATE(gv, (tid & ~15) + i).cv[q];
-                lds[Y.racc_r[0] + q * stride + row * LPB + lane16] = v;
+                double v = bs_class_sum<LPB>(g.cv[q]);
+                if (KIND >= 3) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); }
+                if (lane < LPB) lds[Y.racc_r[r] + q * stride + grp * LPB + lane] = v;
+            }
+#endif
+        }
+#ifdef BB_EMU
+        BB_PASS(cx, tid) {      // (the emulation adds a row's / a wave's lanes of one class in lane order)
+            constexpr int W = KIND <= 2 ? 16 : 64;
+            const int lane = tid & (W - 1), grp = tid / W;
+            if (lane < LPB) {
+                for (int q = 0; q < BR_NCV; ++q) {
+                    double v = 0.0;
+                    for (int i = lane; i < W && (tid & ~(W - 1)) + i < cx.nthr; i += LPB) v += BB_PSTATE(gv, (tid & ~(W - 1)) + i).cv[q];
+                    lds[Y.racc_r[r] + q * stride + grp * LPB + lane] = v;
+                }
             }
         }
-    }
 #endif
+    }
     BB_SYNC(cx);                     // barrier: the partial sums are in LDS
 }
 
@@ -398,14 +419,14 @@ template <int KIND, int TT>
 BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
-    constexpr int LPB = TT / 2;
+    constexpr int LPB = bs_lpb<TT>();
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
     const int g0t = KIND == 2 ? S.tile_g[cx.block] : 0, g1t = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
     const int lspan = bs_lspan(sg, nseg), buf = (int)(step & 1u);
     const int PL = (lspan + cx.nthr - 1) / cx.nthr;           // slots with loglambda pairs: the same for every thread (DPP needs whole waves)
-    const int E = KIND == 1 ? M.E : 1;
+    const int E = (KIND == 1 || KIND == 4) ? M.E : 1;
     double* hs_m = nullptr;
     double* hs_o = nullptr;
     if (A.opt == 0) {
@@ -422,14 +443,13 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
             g.z = bb_d2{0.0, 0.0};
             g.xa = g.xq = g.rm = g.rn = 0.0;
             if (p < lspan) {
-                if (BS_LDESC) bs_desc_l<KIND, TT, true>(M, Y, t, sg, p - sg[0].tbeg, g.st, lds);
-                else br_desc<KIND, 1, false, TT / 2, true>(M, Y, t, sg, nseg, g0t, g1t, p, g.st, 0, lds);
-                if (g.st.meta[0] & BRM_VALID) {
+                bs_desc_l<KIND, TT, true>(M, Y, t, sg, p, g.st, lds);
+                if ((g.st.meta[0] & BRM_VALID) && (g.st.meta[0] & 15) == SK_L) {
                     g.ok = 1;
                     const long long i0 = g.st.i0[0];
-                    bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[0].pad, true, true, g);
+                    bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[g.st.meta[0] >> 12].pad, true, true, g);
                     if (BS_ZKEEP) {
-                        g.z = *(const bb_d2*)(lds + Y.zl + 2 * (p - sg[0].tbeg));
+                        g.z = *(const bb_d2*)(lds + Y.zl + g.st.zoff[0]);
                         double sp0, sg0, sp1, sg1;
                         bb_softplus_sigmoid(g.om.x, &sp0, &sg0);
                         bb_softplus_sigmoid(g.om.y, &sp1, &sg1);
@@ -459,9 +479,9 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 if (mut) {
                     double sp_, sm, sn;
                     br_unit_sw<KIND>(lds, Y, buf, st.uo[0][1], KIND >= 2 ? st.thoff[0] : 0, &sm, &wm);
-                    if (KIND == 1) {
-                        br_unit_sw<KIND>(lds, Y, buf, st.uo[0][0], 0, &sp_, &wp);
-                        br_unit_sw<KIND>(lds, Y, buf, st.uo[0][2], 0, &sn, &wn);
+                    if (KIND == 1 || KIND == 4) {
+                        br_unit_sw<KIND>(lds, Y, buf, st.uo[0][0], KIND >= 3 ? st.thoff[0] : 0, &sp_, &wp);
+                        br_unit_sw<KIND>(lds, Y, buf, st.uo[0][2], KIND >= 3 ? st.thoff[0] : 0, &sn, &wn);
                     } else { sp_ = sn = sm; wp = wn = wm; }
                     ap -= sp_; am -= sm; an -= sn;
                 } else { wp = hp ? lds[L.wbar + pt - 1] : 0.0; wm = lds[L.wbar + pt]; wn = lds[L.wbar + pt + 1]; }
@@ -493,10 +513,11 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 BSG& g = BB_PSTATE(gv, tid);
                 const double As = BS_GROUP_SUM(LPB, gv, tid, xa), Qs = BS_GROUP_SUM(LPB, gv, tid, xq);
                 const int p = tid + k * cx.nthr;
-                if (g.ok && (g.st.meta[0] & BRM_MUT) && ((p - sg[0].tbeg) & (LPB - 1)) == 0) {
-                    const int u = g.st.uo[0][1] - (E > 1 ? g.st.uo[0][1] % E : 0) + e;          // stage index of unit (mutant, e)
+                if (g.ok && (g.st.meta[0] & BRM_MUT) && (p & (LPB - 1)) == 0) {          // (segments start at wave boundaries)
+                    const int u = g.st.uo[0][1] - (E > 1 ? g.st.uo[0][1] % E : 0) + e;          // stage index of unit (mutant [, replicate], e)
                     *(bb_d2*)(aq + 2 * u) = bb_d2{As, Qs};
-                    if (KIND == 2) lds[Y.gas + u] = g.wm * As;          // d/ds_eff of the mutant: its genotype's theta sums these
+                    // hierarchical kinds: d/ds_eff of the unit = w As -- its theta (genotype's; mutant's over the replicates) sums these
+                    if (KIND >= 2) lds[Y.gas + u] = (E == 1 ? g.wm : lds[BR_ST(Y, 2) + buf * Y.SU + u]) * As;
                 }
             }
         }
@@ -506,7 +527,7 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
             g.z = bb_d2{0.0, 0.0};
             if (g.ok) {
                 const long long i0 = g.st.i0[0];
-                if (bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, i0 - sg[0].pad, true, true, g.g0, g.g1, g)) *bad_any = 1;
+                if (bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, i0 - sg[g.st.meta[0] >> 12].pad, true, true, g.g0, g.g1, g)) *bad_any = 1;
                 const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
                 g.z = bs_z(g.mu, g.om, en, &g.sp, &g.sg);
             }
@@ -515,7 +536,7 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
             BSG& g = BB_PSTATE(gv, tid);
             const double zn = BS_NEXT(gv, tid, z.x);
             const int p = tid + k * cx.nthr;
-            if (g.ok) bs_put_l(lds, Y, p - sg[0].tbeg, g.st.meta[0], g.z, zn, g);
+            if (g.ok) bs_put_l<KIND>(lds, Y, g.st.zoff[0], g.st.meta[0], g.z, zn, g);
         }
     }
     BB_STAMP(cx, S, 27);             // (no barrier here: the unit pass forms its first slot's sample before it meets the loglambda lanes)
@@ -529,7 +550,7 @@ BB_DEV bool bs_unit_a(const DevModel& M, const DevState& S, const RunArgs& A, co
     g.ok = 0;
     if (p < lspan) return false;
     BRSt<1>& st = g.st;
-    br_desc<KIND, 1, false, TT / 2, false>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
+    br_desc<KIND, 1, false, bs_lpb<TT>(), false>(M, Y, t, sg, nseg, g0t, g1t, p, st, 0, lds);
     const int meta = st.meta[0];
     if (!(meta & BRM_VALID)) return false;
     const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
@@ -545,10 +566,10 @@ BB_DEV bool bs_unit_a(const DevModel& M, const DevState& S, const RunArgs& A, co
 // part B: gradient from the units' sums and the staged forms of THIS step, optimiser, everything out; the next step's sample, staged
 template <int KIND, int TT>
 BB_DEV bool bs_unit_b(const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, const BRSeg* sg, double* hs_m, double* hs_o,
-                      const BBSlot wslot, unsigned step, double* lds, BSG& g) {
+                      const BBSlot wslot, unsigned step, double* lds, BSG& g, int NBs) {
     const BBLds& L = Y.L;
     const int buf = (int)(step & 1u), nbuf = buf ^ 1;
-    const int E = KIND == 1 ? M.E : 1;
+    const int E = (KIND == 1 || KIND == 4) ? M.E : 1;
     const int* envt = (const int*)(lds + Y.envt);
     const double* aq = lds + Y.hbuf;
     const double* stg = lds + buf * Y.SU;
@@ -564,8 +585,21 @@ BB_DEV bool bs_unit_b(const DevModel& M, const DevState& S, const RunArgs& A, co
         for (int x = 0; x < 2; ++x) {
             if (!(x ? a1 : a0)) continue;
             const int first = st.uo[0][x] & 0xffff, n = st.uo[0][x] >> 16;
+            const double* ge = lds + Y.gas + first;          // (four reads in flight per LDS round trip, as br_update's theta sum)
             double s = 0.0;
-            for (int i = 0; i < n; ++i) s += lds[Y.gas + first + i];
+            int i = 0;
+            for (; i + 4 <= n; i += 4) s += (ge[i] + ge[i + 1]) + (ge[i + 2] + ge[i + 3]);
+            for (; i < n; ++i) s += ge[i];
+            (x ? gl1 : gl0) = s;
+        }
+    } else if (KIND >= 3 && kind == SK_TH_R) {
+        // replicate kinds: d/dtheta[e, m] = sum over the replicates of w As of unit (m, r, e)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (!(x ? a1 : a0)) continue;
+            const int j = st.zoff[0] + x;                      // theta index m E + e; unit (m, r, e): (r NB + m) E + e
+            double s = 0.0;
+            for (int r = 0; r < M.R; ++r) s += lds[Y.gas + r * NBs * E + j];
             (x ? gl1 : gl0) = s;
         }
     } else if (kind < SK_GS) {
@@ -579,7 +613,11 @@ BB_DEV bool bs_unit_b(const DevModel& M, const DevState& S, const RunArgs& A, co
             const bb_d2 AQ = *(const bb_d2*)(aq + 2 * j);
             const double wv = stg[BR_ST(Y, KIND <= 1 ? 1 : 2) + j];
             int nn = TT - 1;
-            if (E > 1) { const int e = (st.uo[0][2] >> (8 * x)) & 255; nn = 0; for (int tt = 0; tt < TT - 1; ++tt) nn += envt[tt + 1] == e ? 1 : 0; }
+            if (E > 1) {
+                const int e = (st.uo[0][2] >> (8 * x)) & 255, tc = KIND == 4 ? ((const int*)(lds + Y.rtab))[4 * st.pt[0]] : 0;          // (unit pairs: pt = replicate)
+                nn = 0;
+                for (int tt = 0; tt < TT - 1; ++tt) nn += envt[tc + tt + 1] == e ? 1 : 0;
+            }
             double acc;
             if (KIND <= 1) acc = kind == SK_S ? wv * AQ.x : wv * AQ.y - (double)nn;
             else if (kind == SK_LS_R) acc = wv * AQ.y - (double)nn;
@@ -632,10 +670,10 @@ BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const R
     BB_PASS(cx, tid) {
         BSG& g = BB_PSTATE(gv, tid);
         bool bad = false;
-        if (g.ok) bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g);
+        if (g.ok) bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g, NB);
         for (int k = k0 + 1; k < P; ++k)
             if (bs_unit_a<KIND, TT>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k * cx.nthr, lspan, step, lds, g))
-                bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g) || bad;
+                bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g, NB) || bad;
         if (bad) *bad_any = 1;
     }
     BB_SYNC(cx);                     // the next step's tables are complete
@@ -656,7 +694,7 @@ __global__ void __launch_bounds__(NT) k_stream(const DevModel* __restrict__ Mp, 
     const unsigned long long c0 = S.ctr[0], c1 = S.ctr[1];
     unsigned long long step0 = c0 > c1 ? c0 : c1;
     step0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(step0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)step0);
-    br_tile_setup<KIND>(cx, M, S, A, Y, NB, NT / 16);
+    br_tile_setup<KIND>(cx, M, S, A, Y, NB, KIND <= 2 ? NT / 16 : NT / 64);
     if (threadIdx.x == 0) *bad_any = 0;
     __syncthreads();
     const bool dead = *ok_slot == 0;

@@ -72,7 +72,18 @@ def vi(bayes_model: BayesModel, advi: ADVI, optimizer=None, seed: int = 0, devic
         m, s = e.posterior()
         ranges = [(lo, hi) for _, lo, hi in e.layout()]
         hier = None
-        if hier_samples and e.hier_units() > 0 and engine_kwargs.get("world_size", 1) == 1:
+        world = int(engine_kwargs.get("world_size", 1))
+        if world > 1:
+            # one process per GPU (torch.distributed initialised by the caller): every rank holds its barcodes' posterior -- gather it, and let
+            # the device-side sampler of `process_hierarchical_samples!` (src/utils.jl:1284-1343) run on the whole vector (round 3 dropped it here)
+            from . import dist
+            n_time = [int(c.shape[0]) for c in bayes_model.counts]
+            n_env = 1 if bayes_model.env_idx is None else int(np.max(bayes_model.env_idx)) + 1
+            m, s = dist.gather_posterior(e, bayes_model.kind, bayes_model.n_neutral, bayes_model.n_bc, n_time, len(n_time), n_env)
+            if hier_samples and e.hier_units() > 0:
+                e.set_params(m, s + np.log(-np.expm1(-s)))          # omega = softplus^-1(sigma)
+                hier = (hier_samples,) + tuple(e.hier_fitness(hier_samples, seed=seed))
+        elif hier_samples and e.hier_units() > 0:
             hier = (hier_samples,) + tuple(e.hier_fitness(hier_samples, seed=seed))
     dist = SimpleNamespace(m=m, σ=s, sigma=s)
     return SimpleNamespace(dist=dist, transform=SimpleNamespace(ranges_out=ranges), hier=hier)

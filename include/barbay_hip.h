@@ -251,7 +251,9 @@ int bb_get_elbo_trace(bb_handle* h, int64_t first_step, int64_t n, double* out);
 /* `process_hierarchical_samples!` of utils.advi_to_df (src/utils.jl:1284-1343) on the device, for the hierarchical
  * models (genotype, replicate, multienv_replicate): for every unit of the theta_tilde block, n_samples draws of
  * theta + exp(logtau) * theta_tilde from the current mean-field posterior; median (reported by the reference under
- * the column name `mean`) and corrected std.  n_samples <= 16384.  median / std: [bb_hier_units(h)]. */
+ * the column name `mean`) and corrected std.  n_samples <= 16384.  median / std: [bb_hier_units(h)].
+ * On a shard of a sharded run (world_size > 1) only the shard's own entries of the parameter arrays are current: pass the gathered
+ * vector through bb_set_params first (a multi-device handle, n_devices > 1, does that itself). */
 int64_t bb_hier_units(const bb_handle* h);
 int bb_hier_fitness(bb_handle* h, int32_t n_samples, uint64_t seed, double* median, double* std);
 

@@ -24,6 +24,8 @@ SYNTH = {
     "multienv_T8": ("multienv", dict(B=300, T=8, n_env=4, n_neutral=40)),
     "replicate_T6": ("replicate", dict(B=301, T=6, n_rep=2, n_neutral=1)),                 # hierarchical kinds under k_res
     "replicate_R3": ("replicate", dict(B=400, T=[6, 8, 4], n_rep=3, n_neutral=20)),        # ... ragged (all T_r even)
+    "replicate_R3_T6": ("replicate", dict(B=400, T=6, n_rep=3, n_neutral=20)),                # ... three replicates with the same T (C3's shape): k_stream where forced
+    "multienv_replicate_R3_T8": ("multienv_replicate", dict(B=240, T=8, n_rep=3, n_env=3, n_neutral=8)),
     "replicate_R4": ("replicate", dict(B=240, T=[8, 8, 6, 6], n_rep=4, n_neutral=12)),           # K + 2 nt1 = 198 moment-row entries: more than a small tile's threads
     "multienv_replicate_T6": ("multienv_replicate", dict(B=150, T=6, n_rep=2, n_env=2, n_neutral=10)),
     "multienv_replicate_R3": ("multienv_replicate", dict(B=300, T=[6, 4, 8], n_rep=3, n_env=3, n_neutral=7)),
@@ -354,19 +356,23 @@ def case_logdensity(lib, name):
         assert (mu0 == mu1).all() and (om0 == om1).all()      # the variational state is untouched
 
 
-def case_p2p_resident(lib, name, world, steps=7):
+def case_p2p_resident(lib, name, world, steps=7, **ekw):
     """Sharded resident launch (bb_p2p_*): `world` handles of one process, stepped in lock step by the emulation's
-    bb_emu_run_group, against the unsharded run -- rows cross ranks through the inboxes exactly as on xGMI."""
+    bb_emu_run_group, against the unsharded run -- rows cross ranks through the inboxes exactly as on xGMI.
+    ekw: samples_per_step / elbo_every -- the MS instances sharded (round 4); the ELBO trace of every rank equals the unsharded one's."""
     import ctypes as C
     from barbay_jl_amd import sharding
     sp = synth(name, seed=4)
-    kw = dict(seed=5, window=4, resum_every=1)
+    kw = dict(seed=5, window=4, resum_every=1, **ekw)
     refs = []
+    trace1 = None
     with make_engine(sp, lib, launch_mode=1, **kw) as e1:
         for _ in range(2):                                             # second pass: restarted from the initial state
             e1.init_meanfield()
             e1.run(steps)
             refs.append(e1.get_params())
+        if ekw.get("elbo_every"):
+            trace1 = e1.elbo_trace(0, steps // ekw["elbo_every"])
     es = [make_engine(sp, lib, rank=r, world_size=world, **kw) for r in range(world)]
     try:
         handles = [e.p2p_export() for e in es]
@@ -397,6 +403,10 @@ def case_p2p_resident(lib, name, world, steps=7):
         for p in per[1:]:
             assert (p[0][glo[0]:glo[1]] == per[0][0][glo[0]:glo[1]]).all() and (p[1][glo[0]:glo[1]] == per[0][1][glo[0]:glo[1]]).all()
         assert all(s["persistent_pairs"] >= 1 for s in st)
+        if trace1 is not None:
+            for e in es:
+                tr = e.elbo_trace(0, len(trace1))
+                assert np.abs(tr - trace1).max() <= 1e-10 * np.abs(trace1).max(), (tr, trace1)
         assert all(e.p2p_enable(False) for e in es)
     finally:
         for e in es:
@@ -408,11 +418,15 @@ def case_multi_device_handle(lib, name, n=2, steps=9, expect_resident=True, **ek
     launches with in-process peer-mapped inboxes; posterior, layout and stats as from a single-device handle."""
     sp = synth(name, seed=4)
     kw = dict(seed=5, window=4, resum_every=1)
+    for k in ("samples_per_step", "elbo_every"):          # (what changes the arithmetic goes to the reference run too)
+        if k in ekw:
+            kw[k] = ekw.pop(k)
     with make_engine(sp, lib, launch_mode=1, **kw) as e1:
         e1.run(steps)
         m1, s1 = e1.posterior()
         p1 = e1.get_params()
         lay1 = e1.layout()
+        trace1 = e1.elbo_trace(0, steps // kw["elbo_every"]) if kw.get("elbo_every") else None
     with make_engine(sp, lib, device_ids=[0] * n, **kw, **ekw) as e:
         assert e.layout() == lay1 and e.D == sp.D
         for _ in range(2):                      # the second pass restarts with the inboxes still holding the first's words
@@ -426,6 +440,9 @@ def case_multi_device_handle(lib, name, n=2, steps=9, expect_resident=True, **ek
         assert (st["resident_kernel"] > 0) == bool(expect_resident), st
         assert np.abs(m - m1).max() < 1e-9 and np.abs(s - s1).max() < 1e-9
         assert np.abs(mu - p1[0]).max() < 1e-9 and np.abs(om - p1[1]).max() < 1e-9
+        if trace1 is not None:
+            tr = e.elbo_trace(0, len(trace1))
+            assert np.abs(tr - trace1).max() <= 1e-10 * np.abs(trace1).max(), (tr, trace1)
         if e.hier_units() > 0:                  # the derived-fitness sampler sees the whole posterior through the group handle
             with make_engine(sp, lib, launch_mode=1, **kw) as eh:
                 eh.set_params(mu, om)

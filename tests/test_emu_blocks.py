@@ -148,13 +148,18 @@ def test_owner_computes_launch_sixteen_groups(emu_lib, monkeypatch, name, nb, nt
 
 
 @pytest.mark.parametrize("name,nb,nthr", [("fitness_neutral_heavy", 64, 64), ("fitness_neutral_heavy", 140, 128), ("multienv_T8", 40, 64),
-                                          ("genotype_T8", 100, 128), ("genotype_T8", 130, 64), ("fitness_T4", 100, 64)])
+                                          ("genotype_T8", 100, 128), ("genotype_T8", 130, 64), ("fitness_T4", 100, 64),
+                                          # round 4: T = 6 (four lanes per barcode, one idle), several replicates, the fifth model
+                                          ("fitness_T6", 90, 128), ("multienv_T6", 75, 64), ("genotype_runs", 110, 128),
+                                          ("replicate_T6", 40, 128), ("replicate_R3_T6", 50, 128), ("replicate_R3_T6", 30, 256),
+                                          ("multienv_replicate_T6", 20, 128), ("multienv_replicate_R3_T8", 30, 256)])
 def test_streaming_resident_launch(emu_lib, monkeypatch, name, nb, nthr):
-    """k_stream (bb_stream.h): tiles with more pair slots than the register file holds -- the state streamed from memory, the draw
-    recomputed in the G pass, contributions summed per thread and by class over the 16-lane rows -- against the two-kernel step and
-    the literal oracle's loop."""
+    """k_stream (bb_stream.h): tiles with more pair slots than the register file holds -- the state streamed from memory in ONE pass per
+    step (the next sample formed inside the G passes, the units' sums by the loglambda lanes), contributions summed per thread and by
+    class over the wave -- against the two-kernel step and the literal oracle's loop.  All five model kinds, T = 4, 6, 8."""
     monkeypatch.setenv("BB_TUNE_NB", str(nb))
     monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_STREAM", "1")
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=3)
     monkeypatch.setenv("BB_TUNE_LEAD", "100")
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=3)
@@ -439,8 +444,11 @@ def test_multi_device_handle_launch_mode_2(emu_lib, monkeypatch):
     monkeypatch.setenv("BB_TUNE_NB", "16")
     monkeypatch.setenv("BB_TUNE_NTHR", "256")
     c.case_multi_device_handle(emu_lib, "fitness_T6", 2, launch_mode=2)
-    with pytest.raises(bb.BarBayHipError, match="launch_mode = 2"):
-        make_engine(c.synth("multienv"), emu_lib, device_ids=[0, 0], launch_mode=2, samples_per_step=2)      # (sharded: single-sample instances only)
+    # several samples per step on a sharded handle: the MS cross-GPU instances since round 4 (odd T: their any-parity form)
+    with make_engine(c.synth("multienv"), emu_lib, device_ids=[0, 0], launch_mode=2, samples_per_step=2) as e:
+        assert e.stats()["resident_kernel"] == 2
+    with pytest.raises(bb.BarBayHipError, match="launch_mode = 2"):          # (the ragged-method pairing runs k_persist only: one sample per step)
+        make_engine(c.synth("replicate_ragged"), emu_lib, device_ids=[0, 0], launch_mode=2, samples_per_step=2, ragged_method=True)
 
 
 def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeypatch):
@@ -449,3 +457,15 @@ def test_multi_device_handle_falls_back_to_the_host_summed_step(emu_lib, monkeyp
     monkeypatch.setenv("BB_TUNE_NTHR", "256")
     c.case_multi_device_handle(emu_lib, "multienv", 2, expect_resident=False, launch_mode=1)
     c.case_multi_device_handle(emu_lib, "genotype", 3, expect_resident=False)     # (genotypes of ~32 mutants do not fit these 16-barcode tiles)
+
+
+@pytest.mark.parametrize("name", ["fitness_T6", "multienv_T8", "genotype_runs", "replicate_T6"])
+def test_sharded_resident_launch_several_samples_and_elbo_trace(emu_lib, monkeypatch, name):
+    """`Turing.ADVI(samples_per_step, ...)` (src/vi.jl:98) and the ELBO trace on a SHARDED run stay in the resident launch (round 4:
+    k_res<.., XG = true, .., MS = true>; every MC sample is an exchange of its own, the inbox epochs count exchanges) -- two and three ranks
+    stepped in lock step by the emulation, and one handle driving two shards; results and trace equal the unsharded run's."""
+    monkeypatch.setenv("BB_TUNE_NB", {"genotype_runs": "24", "multienv_T8": "8", "replicate_T6": "8"}.get(name, "16"))      # (>= 8 tiles per rank of three)
+    monkeypatch.setenv("BB_TUNE_NTHR", "128")
+    c.case_p2p_resident(emu_lib, name, 2, samples_per_step=2, elbo_every=1)
+    c.case_p2p_resident(emu_lib, name, 3, steps=8, samples_per_step=3, elbo_every=2)
+    c.case_multi_device_handle(emu_lib, name, n=2, samples_per_step=2, elbo_every=1)

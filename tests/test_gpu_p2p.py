@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, steps, out_dir):
+def _worker(rank, world, port, case, steps, out_dir, ms=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -31,7 +31,8 @@ def _worker(rank, world, port, case, steps, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sp = c.synth(case, seed=4)
-    e = make_engine(sp, None, seed=5, window=4, resum_every=1, rank=rank, world_size=world, device=0)
+    ekw = dict(samples_per_step=2, elbo_every=1) if ms else {}
+    e = make_engine(sp, None, seed=5, window=4, resum_every=1, rank=rank, world_size=world, device=0, **ekw)
     on = bb.dist.setup_p2p(e)
     st0 = e.stats()
     for _ in range(2):            # the second pass restarts from the initial state with the inboxes still holding the first's words
@@ -42,7 +43,8 @@ def _worker(rank, world, port, case, steps, out_dir):
     st = e.stats()
     if rank == 0:
         np.savez(os.path.join(out_dir, "sharded.npz"), mean=mean, sigma=sigma, on=on, pairs=st["persistent_pairs"],
-                 launches=st["launches_last_run"], blocks=st0["n_blocks"])
+                 launches=st["launches_last_run"], blocks=st0["n_blocks"], name=e.kernel_name(),
+                 trace=e.elbo_trace(0, steps) if ms else np.zeros(0))
     dist.barrier()
     e.close()
     dist.destroy_process_group()
@@ -65,3 +67,25 @@ def test_two_processes_one_gpu(hip_lib, tmp_path, monkeypatch, case):
     got = np.load(tmp_path / "sharded.npz")
     assert bool(got["on"]) and int(got["pairs"]) == 1 and int(got["launches"]) == 1     # the resident launch really ran
     assert np.abs(got["mean"] - m1).max() < 1e-9 and np.abs(got["sigma"] - s1).max() < 1e-9
+
+
+@pytest.mark.parametrize("case", ["fitness_T6", "genotype_runs"])
+def test_two_processes_one_gpu_several_samples_and_elbo_trace(hip_lib, tmp_path, monkeypatch, case):
+    """`Turing.ADVI(2, ...)` (src/vi.jl:98) with the ELBO recorded every step on a SHARDED run: the resident launch's MS + cross-GPU
+    instance (k_res<.., true, 0, .., true>; round 3 dropped such runs to two kernels + RCCL) -- posterior and trace equal the unsharded run's."""
+    import _cases as c
+    from conftest import make_engine
+    monkeypatch.setenv("BB_TUNE_NB", "24" if case == "genotype_runs" else "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    steps = 9
+    sp = c.synth(case, seed=4)
+    with make_engine(sp, hip_lib, seed=5, window=4, resum_every=1, launch_mode=1, samples_per_step=2, elbo_every=1) as e1:
+        e1.run(steps)
+        m1, s1 = e1.posterior()
+        t1 = e1.elbo_trace(0, steps)
+    mp.spawn(_worker, args=(2, _free_port(), case, steps, str(tmp_path), True), nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    assert bool(got["on"]) and int(got["pairs"]) == 1 and int(got["launches"]) == 1
+    assert str(got["name"]).startswith("k_res<") and str(got["name"]).endswith(",true>") and ",true,0," in str(got["name"]), str(got["name"])
+    assert np.abs(got["mean"] - m1).max() < 1e-9 and np.abs(got["sigma"] - s1).max() < 1e-9
+    assert np.abs(got["trace"] - t1).max() <= 1e-10 * np.abs(t1).max()

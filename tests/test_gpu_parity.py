@@ -322,10 +322,15 @@ def test_owner_computes_launch_genotype(hip_lib, name):
 
 
 @pytest.mark.parametrize("name,nb,nthr", [("fitness_neutral_heavy", 140, 1024), ("multienv_T8", 150, 512), ("genotype_T8", 500, 1024), ("genotype_T8", 250, 512),
-                                          ("fitness_T4", 333, 1024)])
+                                          ("fitness_T4", 333, 1024),
+                                          # round 4: T = 6 (four lanes per barcode, one idle), several replicates (kinds 3, 4)
+                                          ("fitness_T6", 350, 1024), ("multienv_T6", 300, 1024), ("genotype_runs", 400, 1024),
+                                          ("replicate_T6", 150, 1024), ("replicate_R3_T6", 100, 512), ("replicate_R3_T6", 200, 1024),
+                                          ("multienv_replicate_T6", 75, 512), ("multienv_replicate_R3_T8", 80, 1024)])
 def test_streaming_resident_launch(hip_lib, monkeypatch, name, nb, nthr):
-    """k_stream (bb_stream.h): tiles with more pair slots than the register file holds -- the state streamed from memory, the draw
-    recomputed in the G pass -- against the two-kernel step and the literal oracle's loop (small shapes forced into few large tiles)."""
+    """k_stream (bb_stream.h): tiles with more pair slots than the register file holds -- the state streamed from memory in one pass per
+    step, the next sample formed inside the G passes, the units' sums by the loglambda lanes -- against the two-kernel step and the literal
+    oracle's loop (small shapes forced into few large tiles).  All five model kinds."""
     monkeypatch.setenv("BB_TUNE_NB", str(nb))
     monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
     monkeypatch.setenv("BB_TUNE_STREAM", "1")
@@ -403,6 +408,15 @@ def test_multi_device_handle(hip_lib, monkeypatch, name, n):
     monkeypatch.setenv("BB_TUNE_NB", "16")          # >= 8 tiles per shard; all shards' small grids fit the one GPU together
     monkeypatch.setenv("BB_TUNE_NTHR", "512")
     c.case_multi_device_handle(hip_lib, name, n)
+
+
+@pytest.mark.parametrize("name", ["fitness_T6", "genotype_runs"])
+def test_multi_device_handle_several_samples_and_elbo_trace(hip_lib, monkeypatch, name):
+    """one handle, two shards, samples_per_step = 2 and the ELBO every step: resident launches (MS + cross-GPU instances), not the
+    host-summed two-kernel fallback of round 3"""
+    monkeypatch.setenv("BB_TUNE_NB", "24" if name == "genotype_runs" else "16")
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    c.case_multi_device_handle(hip_lib, name, 2, samples_per_step=2, elbo_every=1)
 
 
 def test_multi_device_handle_host_summed_fallback(hip_lib, monkeypatch):
