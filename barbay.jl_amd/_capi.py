@@ -24,7 +24,7 @@ BB_ERR_NONFINITE = -5
 
 EXPORTS = [
     "bb_version", "bb_last_error", "bb_default_opts", "bb_create", "bb_destroy", "bb_num_latents",
-    "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_get_permutation", "bb_run", "bb_run_profiled",
+    "bb_get_layout", "bb_init_meanfield", "bb_set_params", "bb_get_params", "bb_get_permutation", "bb_get_owned", "bb_run", "bb_run_profiled",
     "bb_get_posterior", "bb_elbo_grad", "bb_logdensity_grad", "bb_get_elbo_trace", "bb_debug_normals", "bb_debug_stamps", "bb_get_stats", "bb_kernel_name",
     "bb_comm_make_id", "bb_comm_init", "bb_step_moments", "bb_step_apply", "bb_hier_units", "bb_hier_fitness", "bb_p2p_export", "bb_p2p_import", "bb_p2p_selftest", "bb_p2p_enable",
 ]
@@ -100,6 +100,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.bb_get_params.argtypes = [vp, _dp, _dp]
     if hasattr(lib, "bb_get_permutation"):      # (A/B builds of older sources, tools/xp.py)
         lib.bb_get_permutation.argtypes = [vp, C.POINTER(C.c_int64)]
+    if hasattr(lib, "bb_get_owned"):
+        lib.bb_get_owned.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.bb_run.argtypes = [vp, C.c_int64]
     lib.bb_run_profiled.argtypes = [vp, C.c_int64]
     lib.bb_get_posterior.argtypes = [vp, _dp, _dp]
@@ -281,6 +283,14 @@ class Engine:
         out = np.empty(self.D, dtype=np.int64)
         self._check(self._lib.bb_get_permutation(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
+
+    def owned(self) -> np.ndarray:
+        """The caller's flat indices of the latents this handle owns on a sharded run (`bb_get_owned`): its barcodes' latents and,
+        genotype model, theta of its own genotypes -- not the replicated global blocks."""
+        out = np.empty(self.D, dtype=np.int64)
+        n = C.c_int64(0)
+        self._check(self._lib.bb_get_owned(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)))
+        return out[:n.value].copy()
 
     def run(self, n_steps: int):
         self._check(self._lib.bb_run(self._h, int(n_steps)))

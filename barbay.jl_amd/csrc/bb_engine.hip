@@ -428,6 +428,10 @@ static void hist_rows(bb_handle* h) {
 }
 
 static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out);
+// bb_create -> create_inner (and the shards of a multi-device handle): lay the loglambda block out in FRONT of the per-genotype / per-mutant
+// blocks (the handle's internal order; the caller's stays the reference's source order) -- see bb_create
+static thread_local bool g_loglambda_first = false;
+static void owned_ranges(const bb_handle* sh, std::vector<std::pair<long long, long long>>& out);
 static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
 static int theta_sync_local(bb_handle* const* hs, int n);
 #ifndef BB_EMU
@@ -1176,12 +1180,13 @@ static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
         add_block(h, "logsigma_bc", BK_LS, M.nb * M.E, &off);
     } else {
         const long long E_ = M.kind == BB_MODEL_MULTIENV_REPLICATE ? M.E : 1;
+        if (g_loglambda_first) add_block(h, "loglambda", BK_L, n_l, &off);          // (internal order only: bb_create)
         add_block(h, "theta", BK_S, M.kind == BB_MODEL_GENOTYPE ? M.G : M.nb * E_, &off);
         add_block(h, "theta_tilde", BK_TT, M.nb * M.R * E_, &off);
         add_block(h, "logtau", BK_LT, M.nb * M.R * E_, &off);
         add_block(h, "logsigma_bc", BK_LS, M.nb * M.R * E_, &off);
     }
-    add_block(h, "loglambda", BK_L, n_l, &off);
+    if (!(g_loglambda_first && M.kind >= BB_MODEL_GENOTYPE)) add_block(h, "loglambda", BK_L, n_l, &off);
     M.D = off;
     M.Dp = (off + 7) & ~7ll;
     for (int r = 0, o = 0; r < M.R; ++r) { M.off_l[r] = M.blk_lo[BK_L] + (long long)o * M.B; o += M.T[r]; }
@@ -1428,54 +1433,102 @@ static void perm_scatter(const bb_handle* h, const double* internal, double* cal
 // INTERNAL index (bb_debug_normals likewise).
 extern "C" int bb_create(const bb_model_desc* md, const bb_advi_opts* opts, bb_handle** out) {
     if (!md || !opts || !out) return bb_fail(BB_ERR_INVALID, "null argument");
-    bool regroup = md->kind == BB_MODEL_GENOTYPE && md->geno_idx && md->n_bc > 1 && md->n_geno >= 1 && md->n_neutral >= 1 && md->n_time &&
-                   md->counts && md->n_rep == 1 && !getenv("BB_NO_REGROUP");
+    const bool geno_ok = md->kind == BB_MODEL_GENOTYPE && md->geno_idx && md->n_bc > 1 && md->n_geno >= 1 && md->n_neutral >= 1 && md->n_time &&
+                         md->counts && md->n_rep == 1 && md->n_time[0] >= 2 && md->n_time[0] <= 255;
+    bool regroup = geno_ok && !getenv("BB_NO_REGROUP");
     if (regroup) {
         bool sorted = true, valid = true;
         for (long long m = 0; m < md->n_bc && valid; ++m) {
             if (md->geno_idx[m] < 0 || md->geno_idx[m] >= md->n_geno) valid = false;
             else if (m > 0 && md->geno_idx[m] < md->geno_idx[m - 1]) sorted = false;
         }
-        regroup = valid && !sorted && md->n_time[0] >= 2 && md->n_time[0] <= 255;      // (anything invalid: create_inner says what)
+        regroup = valid && !sorted;      // (anything invalid: create_inner says what)
     }
-    if (!regroup) return create_inner(md, opts, out);
+    // Round 4: the genotype model's flat vector s_pop | logsigma_pop | theta (G) | theta_tilde | logtau | logsigma_bc (n_bc each) | loglambda puts
+    // loglambda at an ODD index whenever G + n_bc is odd; k_res's pairs (b, 2k), (b, 2k+1) are then not pairs (2q, 2q+1) of the flat index and
+    // the any-parity instances ran (two Philox draws in divergent lanes, 8-byte accesses, 40 spilled registers: C5's rank shape 14.95 against
+    // 12.8 us).  The library owns an internal order anyway: it lays loglambda out right behind the two global blocks (offset 2 (T - 1): even
+    // for even T) and presents the reference's order at every entry point, as for the regrouped mutants.  BB_NO_REORDER=1: as handed over.
+    const bool lfirst = geno_ok && !(md->n_time[0] & 1) && ((md->n_geno + md->n_bc) & 1) && !getenv("BB_NO_REORDER");
+    if (!regroup && !lfirst) return create_inner(md, opts, out);
     const long long nn = md->n_neutral, nb = md->n_bc, B = nn + nb;
     const int T = md->n_time[0];
     std::vector<int> perm((size_t)nb);
     for (long long m = 0; m < nb; ++m) perm[(size_t)m] = (int)m;
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return md->geno_idx[a] < md->geno_idx[b]; });
+    if (regroup) std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return md->geno_idx[a] < md->geno_idx[b]; });
     auto src = [&](long long b) { return b < nn ? b : nn + perm[(size_t)(b - nn)]; };
-    std::vector<int64_t> counts2((size_t)B * T);
-    for (long long b = 0; b < B; ++b) memcpy(&counts2[(size_t)b * T], md->counts + src(b) * T, (size_t)T * sizeof(int64_t));
-    std::vector<int32_t> geno2((size_t)nb);
-    for (long long m = 0; m < nb; ++m) geno2[(size_t)m] = md->geno_idx[perm[(size_t)m]];
     bb_model_desc md2 = *md;
-    md2.counts = counts2.data();
-    md2.geno_idx = geno2.data();
-    // Matrix-form priors of the per-mutant and per-(time, barcode) blocks move with their barcodes
+    std::vector<int64_t> counts2;
+    std::vector<int32_t> geno2;
     std::vector<double> lsm, lss, llm, lls;
-    if (md->logsigma_bc_prior.mean && md->logsigma_bc_prior.std && md->logsigma_bc_prior.n == nb && nb > 1) {
-        lsm.resize((size_t)nb); lss.resize((size_t)nb);
-        for (long long m = 0; m < nb; ++m) { lsm[(size_t)m] = md->logsigma_bc_prior.mean[perm[(size_t)m]]; lss[(size_t)m] = md->logsigma_bc_prior.std[perm[(size_t)m]]; }
-        md2.logsigma_bc_prior.mean = lsm.data(); md2.logsigma_bc_prior.std = lss.data();
+    if (regroup) {
+        counts2.resize((size_t)B * T);
+        for (long long b = 0; b < B; ++b) memcpy(&counts2[(size_t)b * T], md->counts + src(b) * T, (size_t)T * sizeof(int64_t));
+        geno2.resize((size_t)nb);
+        for (long long m = 0; m < nb; ++m) geno2[(size_t)m] = md->geno_idx[perm[(size_t)m]];
+        md2.counts = counts2.data();
+        md2.geno_idx = geno2.data();
+        // Matrix-form priors of the per-mutant and per-(time, barcode) blocks move with their barcodes
+        if (md->logsigma_bc_prior.mean && md->logsigma_bc_prior.std && md->logsigma_bc_prior.n == nb && nb > 1) {
+            lsm.resize((size_t)nb); lss.resize((size_t)nb);
+            for (long long m = 0; m < nb; ++m) { lsm[(size_t)m] = md->logsigma_bc_prior.mean[perm[(size_t)m]]; lss[(size_t)m] = md->logsigma_bc_prior.std[perm[(size_t)m]]; }
+            md2.logsigma_bc_prior.mean = lsm.data(); md2.logsigma_bc_prior.std = lss.data();
+        }
+        if (md->loglambda_prior.mean && md->loglambda_prior.std && md->loglambda_prior.n == (int64_t)B * T && B * T > 1) {
+            llm.resize((size_t)B * T); lls.resize((size_t)B * T);
+            for (long long b = 0; b < B; ++b)
+                for (int t = 0; t < T; ++t) { llm[(size_t)b * T + t] = md->loglambda_prior.mean[src(b) * T + t]; lls[(size_t)b * T + t] = md->loglambda_prior.std[src(b) * T + t]; }
+            md2.loglambda_prior.mean = llm.data(); md2.loglambda_prior.std = lls.data();
+        }
     }
-    if (md->loglambda_prior.mean && md->loglambda_prior.std && md->loglambda_prior.n == (int64_t)B * T && B * T > 1) {
-        llm.resize((size_t)B * T); lls.resize((size_t)B * T);
-        for (long long b = 0; b < B; ++b)
-            for (int t = 0; t < T; ++t) { llm[(size_t)b * T + t] = md->loglambda_prior.mean[src(b) * T + t]; lls[(size_t)b * T + t] = md->loglambda_prior.std[src(b) * T + t]; }
-        md2.loglambda_prior.mean = llm.data(); md2.loglambda_prior.std = lls.data();
-    }
+    g_loglambda_first = lfirst;
     int rc = create_inner(&md2, opts, out);
+    g_loglambda_first = false;
     if (rc) return rc;
     bb_handle* h = *out;
     const DevModel& M = h->M;
-    h->perm_m = perm;
+    if (regroup) h->perm_m = perm;
+    // the caller's layout: the reference's source order (what bb_get_layout reports), and the map internal -> caller
+    const int order[BK_COUNT] = {BK_SPOP, BK_LSPOP, BK_S, BK_TT, BK_LT, BK_LS, BK_L};
+    long long clo[BK_COUNT] = {0};
+    {
+        std::vector<bb_block_range> cb;
+        long long off = 0;
+        for (int k : order) {
+            bb_block_range b;
+            memset(&b, 0, sizeof b);
+            for (const bb_block_range& ib : h->blocks) if (ib.lo == M.blk_lo[k] && ib.hi == M.blk_hi[k] && ib.hi > ib.lo) snprintf(b.name, sizeof b.name, "%s", ib.name);
+            clo[k] = off;
+            b.lo = off;
+            b.hi = off + (M.blk_hi[k] - M.blk_lo[k]);
+            off = b.hi;
+            cb.push_back(b);
+        }
+        h->blocks = cb;
+    }
     h->cidx.resize((size_t)M.D);
-    for (long long i = 0; i < M.D; ++i) h->cidx[(size_t)i] = i;
-    for (int k : {BK_TT, BK_LT, BK_LS})
-        for (long long m = 0; m < nb; ++m) h->cidx[(size_t)(M.blk_lo[k] + m)] = M.blk_lo[k] + perm[(size_t)m];
-    for (long long b = nn; b < B; ++b)
-        for (int t = 0; t < T; ++t) h->cidx[(size_t)(M.blk_lo[BK_L] + b * T + t)] = M.blk_lo[BK_L] + src(b) * T + t;
+    for (int k : order)
+        for (long long j = 0; j < M.blk_hi[k] - M.blk_lo[k]; ++j) h->cidx[(size_t)(M.blk_lo[k] + j)] = clo[k] + j;
+    if (regroup) {
+        for (int k : {BK_TT, BK_LT, BK_LS})
+            for (long long m = 0; m < nb; ++m) h->cidx[(size_t)(M.blk_lo[k] + m)] = clo[k] + perm[(size_t)m];
+        for (long long b = nn; b < B; ++b)
+            for (int t = 0; t < T; ++t) h->cidx[(size_t)(M.blk_lo[BK_L] + b * T + t)] = clo[BK_L] + src(b) * T + t;
+    }
+    return BB_OK;
+}
+
+// caller indices of the latents THIS handle owns on a sharded run (its barcodes' latents; genotype model: theta of its own genotypes) -- what
+// a gather of the ranks' posteriors takes from this rank.  The replicated global blocks are not in the list.  idx: [bb_num_latents(h)].
+extern "C" int bb_get_owned(bb_handle* h, int64_t* idx, int64_t* n) {
+    if (!h || !idx || !n) return bb_fail(BB_ERR_INVALID, "null argument");
+    std::vector<std::pair<long long, long long>> rg;
+    if (h->shards.empty()) owned_ranges(h, rg);
+    else for (bb_handle* sh : h->shards) owned_ranges(sh, rg);
+    int64_t c = 0;
+    for (auto& r : rg)
+        for (long long i = r.first; i < r.second; ++i) idx[c++] = h->cidx.empty() ? i : h->cidx[(size_t)i];
+    *n = c;
     return BB_OK;
 }
 

@@ -17,7 +17,6 @@ from typing import Dict, Sequence, Tuple
 
 import numpy as np
 
-from .sharding import owned_indices
 
 
 def init_rccl(engine) -> None:
@@ -112,13 +111,9 @@ def gather_posterior(engine, kind: str, n_neutral: int, n_bc: int, n_time: Seque
                      n_env: int = 1) -> Tuple[np.ndarray, np.ndarray]:
     import torch.distributed as dist
     mean, sigma = engine.posterior()
-    st = engine.stats()
-    layout: Dict[str, Tuple[int, int]] = {n: (lo, hi) for n, lo, hi in engine.layout()}
-    ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env,
-                       geno_range=(int(st["geno_lo"]), int(st["geno_hi"])) if kind == "genotype" else None)
-    # shard_lo / shard_hi / geno_lo / geno_hi describe the handle's INTERNAL order (the genotype model's mutants regrouped by
-    # bb_create); posterior() presents the CALLER's order: map the owned entries across (identity when nothing was regrouped)
-    ix = engine.permutation()[ix]
+    # the library names the entries this rank owns, in the CALLER's order (bb_get_owned): shard and genotype ranges live in the handle's
+    # internal order (mutants regrouped by genotype, loglambda in front of theta where that keeps its pairs aligned)
+    ix = engine.owned()
     parts = [None] * dist.get_world_size()
     dist.all_gather_object(parts, (ix, mean[ix], sigma[ix]))
     for i, m, s in parts:

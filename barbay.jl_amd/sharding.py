@@ -53,15 +53,16 @@ def owned_indices(kind: str, layout: Dict[str, Tuple[int, int]], b_lo: int, b_hi
 
 def gather_params(per_rank: Sequence[np.ndarray], stats: Sequence[dict], kind: str, layout: Dict[str, Tuple[int, int]],
                   n_neutral: int, n_bc: int, n_time: Sequence[int], n_rep: int = 1, n_env: int = 1,
-                  permutations: Sequence[np.ndarray] | None = None) -> np.ndarray:
-    """Full flat vector from per-rank vectors: replicated blocks from rank 0, owned slices from their rank.  The stats' shard /
-    genotype ranges are in the handles' INTERNAL order; `permutations[r]` = rank r's `engine.permutation()` maps them to the caller's
-    order the vectors are in (needed whenever bb_create regrouped the genotype model's mutants; None: nothing was regrouped)."""
+                  owned: Sequence[np.ndarray] | None = None) -> np.ndarray:
+    """Full flat vector from per-rank vectors: replicated blocks from rank 0, owned entries from their rank.  `owned[r]` = rank r's
+    `engine.owned()` (the library's own word, in the caller's order -- needed whenever the handle's internal order differs from the
+    caller's: genotype model); None: the ranges are worked out here from the stats' shard / genotype ranges (identity order)."""
     out = np.array(per_rank[0], copy=True)
     for r, (v, st) in enumerate(zip(per_rank, stats)):
-        ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env,
-                           geno_range=(int(st["geno_lo"]), int(st["geno_hi"])) if kind == "genotype" else None)
-        if permutations is not None:
-            ix = np.asarray(permutations[r])[ix]
+        if owned is not None:
+            ix = np.asarray(owned[r])
+        else:
+            ix = owned_indices(kind, layout, int(st["shard_lo"]), int(st["shard_hi"]), n_neutral, n_bc, n_time, n_rep, n_env,
+                               geno_range=(int(st["geno_lo"]), int(st["geno_hi"])) if kind == "genotype" else None)
         out[ix] = v[ix]
     return out

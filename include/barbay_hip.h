@@ -190,10 +190,15 @@ int bb_get_params(bb_handle* h, double* mu, double* omega);
 /* Genotype model: the reference hands barcodes over in order of appearance (utils.data_to_arrays, src/utils.jl:692-731), so a
  * genotype's mutants are scattered over geno_idx.  The library then groups them itself (stable sort of the mutants by genotype:
  * the resident launch and genotype-aligned shards need consecutive runs), works in that order and presents the CALLER's order at
- * every entry point that takes or returns a latent vector.  caller_index[i] = the caller's flat index of the handle's internal
+ * every entry point that takes or returns a latent vector.  Likewise the loglambda block: where n_geno + n_bc is odd it would start at
+ * an odd flat index, so internally it sits in front of the theta block (the resident launch's 16-byte pairs stay whole).  caller_index[i] = the caller's flat index of the handle's internal
  * latent i (identity when nothing was regrouped); the engine's normal stream (bb_debug_normals, bb_elbo_grad with eps = NULL,
  * bb_run) is keyed by the INTERNAL index.  caller_index: [bb_num_latents(h)]. */
 int bb_get_permutation(bb_handle* h, int64_t* caller_index);
+/* Sharded runs: the CALLER's flat indices of the latents this handle owns -- its barcodes' loglambda and per-mutant latents, genotype model:
+ * theta of its own genotypes (bb_stats.geno_lo / geno_hi) -- i.e. what a gather of the ranks' posteriors takes from this rank; the
+ * replicated global blocks are not listed (every rank holds them).  idx: [bb_num_latents(h)], *n entries are written. */
+int bb_get_owned(bb_handle* h, int64_t* idx, int64_t* n);
 
 /* AdvancedVI.optimize!: n_steps iterations of
  *   grad(-ELBO) with S reparameterised samples -> optimiser -> theta -= delta. */
