@@ -188,7 +188,7 @@ BRLay br_layout(const DevModel& M, int NB, int NT, int P, int xg_rows, bool own_
     for (int i = 0; i < 6; ++i) { Y.st[i] = o; if (i < Y.nst) o += Y.stw; }
     o = (o + 1) & ~1;
     // (k_res: two terms per mutant as one 16-byte entry, br_theta_pre; k_stream: w As of every unit of the hierarchical kinds, bs_update_l)
-    Y.gas = o;     o += stream ? (M.kind >= 2 ? Y.SU : 0) : (M.kind == 2 ? 2 * Y.SU : 0);
+    Y.gas = o;     o += stream ? (M.kind >= 2 ? Y.SU : 0) : ((M.kind == 2 || M.kind == 3) ? 2 * Y.SU : 0);
     Y.gix = o;     o += M.kind == 2 ? Y.SU + 1 : 0;
     o = (o + 1) & ~1;
     // One transient region, users that never overlap in time: the transposed moment contributions (M pass -> row sums), then --
@@ -1118,9 +1118,15 @@ BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
 #ifndef BR_TH_PRE
 #define BR_TH_PRE 1
 #endif
+// (replicate model, BR_TH_PRE3: the same for d/dtheta_m = sum over the replicates of w As of unit (m, r) -- the theta thread no longer walks
+//  R barcode rows, it adds R entries up)
+#ifndef BR_TH_PRE3
+#define BR_TH_PRE3 1
+#endif
+template <int KIND> BB_DEV constexpr bool br_th_pre() { return (KIND == 2 && BR_TH_PRE) || (KIND == 3 && BR_TH_PRE3); }
 template <int KIND, int P, int TT = 0>
 BB_DEV void br_theta_pre(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* stv, int buf) {
-    if (KIND != 2 || !BR_TH_PRE) return;
+    if (!br_th_pre<KIND>()) return;
     double* lds = cx.lds;
     BB_PASS(cx, tid) {
         BRSt<P>& st = BB_PSTATE(stv, tid);
@@ -1128,15 +1134,17 @@ BB_DEV void br_theta_pre(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* 
         for (int k = 0; k < P; ++k) {
             const int meta = st.meta[k];
             if ((meta & 15) != SK_TT_R || !(meta & BRM_VALID)) continue;
-            // the theta_tilde thread of a mutant (idle here) leaves the mutant's two terms; its genotype's theta thread adds its members' up
-            // at the start of the G pass (a theta thread walking its ~40 members' rows itself, here, took 12 k cycles and held its tile's
-            // exchange up: profiles/r04c_theta_pre)
-            const int T = TT ? TT : M.T[0];
-            const double* zbuf = lds + Y.zl + buf * Y.NBT + Y.zr0[0];
+            // the theta_tilde thread of a unit (idle here) leaves the unit's two terms; its theta thread adds its members' up at the start
+            // of the G pass (a theta thread walking its ~40 members' rows itself, here, took 12 k cycles and held its tile's exchange up:
+            // profiles/r04c_theta_pre)
+            const int* rt = (const int*)(lds + Y.rtab) + 4 * (KIND == 2 ? 0 : st.pt[k]);          // (unit pairs: pt = replicate)
+            const int T = TT ? TT : rt[2];
+            const double* zbuf = lds + Y.zl + buf * Y.NBT + (KIND == 2 ? Y.zr0[0] : rt[1]);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 if (!(meta & (x ? BRM_A1 : BRM_A0))) continue;
-                const int j = st.zoff[k] + x, bl = st.uo[k][x], th = j - ((st.uo[k][2] >> (16 * x)) & 0xffff);
+                const int j = st.zoff[k] + x, bl = st.uo[k][x];
+                const int th = KIND == 2 ? j - ((st.uo[k][2] >> (16 * x)) & 0xffff) : st.thoff[k];
                 double sv, wv;
                 br_unit_sw<KIND>(lds, Y, buf, j, th, &sv, &wv);
                 const double* zr = zbuf + bl * (T + 1);
@@ -1265,6 +1273,19 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                     zx[x] = stg[BR_ST(Y, br_stage_raw<KIND>(kind)) + j];
                     // replicates whose rows the latent's gradient sums over: its own; theta: all of them
                     const bool is_th = KIND >= 3 && kind == SK_TH_R;
+                    if (KIND == 3 && BR_TH_PRE3 && is_th) {          // (br_theta_pre: the units' terms w [..], w are in LDS since the exchange's shadow)
+                        double acc = 0.0;
+                        for (int r = 0; r < M.R; ++r) {
+                            const int* rt = (const int*)(lds + Y.rtab) + 4 * r;
+                            const int T = TT ? TT : rt[2];
+                            double csum = 0.0;
+                            for (int tt = 0; tt < T - 1; ++tt) csum += lds[L.cc + rt[0] + tt];
+                            const bb_d2 ge = *(const bb_d2*)(lds + Y.gas + 2 * (r * NBs + j));
+                            acc += ge.x - ge.y * csum;
+                        }
+                        gx[x] = acc;
+                        continue;
+                    }
                     const int r0 = KIND <= 1 ? 0 : (is_th ? 0 : st.pt[k]), r1 = KIND <= 1 ? 1 : (is_th ? M.R : r0 + 1);
                     double acc = 0.0;
                     for (int r = r0; r < r1; ++r) {

@@ -19,6 +19,7 @@ CFG = {
     "C5 genotype_fitness_normal 200000x8 G=5000": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45),
     "C5 as ONE of its 8 ranks: genotype_fitness_normal 25000x8 G=625 (200000/8 barcodes, 5000/8 genotypes)":
         lambda: synth.genotype_fitness_normal(25_000, 8, 625, 45),
+    "(no BASELINE config) replicate_fitness_normal 80000x6x3, beyond the register file": lambda: synth.replicate_fitness_normal(80_000, 6, 3, 43),
     "C5 at about the largest size whose state fits one GPU's registers: genotype_fitness_normal 50000x8 G=1250": lambda: synth.genotype_fitness_normal(50_000, 8, 1_250, 45),
     "(no BASELINE config) multienv_replicate_fitness_normal 12000x(6,5,6) E=3": lambda: synth.multienv_replicate_fitness_normal(),
 }
@@ -26,7 +27,7 @@ steps = int(os.environ.get("STEPS", 4000))
 
 
 def st0_fast(wl):
-    return wl.n_bc < 150_000          # (full C5 runs the two-kernel step, ~130 us each: fewer steps keep the script short)
+    return wl.n_bc < 70_000          # (full C5 runs the two-kernel step, ~130 us each: fewer steps keep the script short)
 
 
 for name, mk in CFG.items():
@@ -43,6 +44,7 @@ for name, mk in CFG.items():
     print(json.dumps({"config": name, "steps_per_s": round(n / dt, 1), "us_per_step": round(dt / n * 1e6, 2),
                       "n_latents": st["n_latents"], "bytes_per_step": st["bytes_per_step"],
                       "frac_hbm_peak": round(st["bytes_per_step"] * n / dt / 8e12, 4),
-                      "resident_launch_pairs": st["persistent_pairs"], "resident_kernel": {0: "none (two kernels per step)", 1: "k_persist", 2: "k_res", 3: "k_stream"}[st["resident_kernel"]], "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
+                      "resident_launch_pairs": st["persistent_pairs"], "resident_kernel": {0: "none (two kernels per step)", 1: "k_persist", 2: "k_res", 3: "k_stream"}[st["resident_kernel"]],
+                      "kernel_instance": e.kernel_name(), "workgroups": st["n_blocks"], "threads": st["block_threads"]}),
           flush=True)
     e.close()

@@ -35,6 +35,12 @@ for src, dst in ((f"{tag}_bench.json", "bench.json"), (f"{tag}_bench20.json", "b
     cp(src, dst)
 for c in ("C3", "C4", "C5rank"):
     cp(f"{tag}_validate_{c}.json", f"validate_{c}_3000_iterations.json")
+for n in (2, 4):          # (round 4: the N > 1 bench line, short form against long launches -- one-GPU rehearsal)
+    cp(f"{tag}_rehearsal{n}_20.json", f"bench_{n}ranks_one_gpu_rehearsal_20_steps_warmup_5.json")
+    cp(f"{tag}_rehearsal{n}_4000.json", f"bench_{n}ranks_one_gpu_rehearsal_4000_steps.json")
+for src, dst in ((f"{tag}_stream_replicates.txt", "k_stream_replicate_80000x6x3.txt"), (f"{tag}_stamps_C5.txt", "stamps_C5_k_stream.txt"),
+                 (f"{tag}_stamps_C5rank.txt", "stamps_C5rank.txt"), (f"{tag}_stamps_C3.txt", "stamps_C3.txt")):
+    cp(src, dst)
 # (the traffic record names the COMMITTED directory its counter rows sit in, not the scratch tag; it is restamped only when this round's
 #  counter passes exist -- a partial round must neither crash the collection nor point bench.py's replayed `traffic` at a directory
 #  without the matching rows: ADVICE r03)
@@ -60,7 +66,7 @@ for nm, d, k in (("pmc_FETCH_SIZE_k_res.csv", f"{tag}/pmc_fetch", "k_res"), ("pm
         w.writeheader()
         w.writerows(rows)
 lines = []
-for cfg in ("C3", "C4", "C5rank", "C5"):
+for cfg in ("C3", "C4", "C5rank", "C5rank_plain", "C5"):
     f = newest(f"{tag}_trace_{cfg}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(D, f"kernel_stats_{cfg}.csv"))
