@@ -21,7 +21,9 @@ wl = {"C2": lambda: synth.fitness_normal(50_000, 8, 42), "C3": lambda: synth.rep
       "C4": lambda: synth.multienv_fitness_normal(20_000, 6, (1, 1, 2, 3, 4, 1), 44),
       # (626 genotypes: n_geno + n_bc even, the handle's internal order is the caller's -- the port draws by the caller's flat index, the
       #  engine by its internal one, and "the same Philox stream" needs the two to coincide)
-      "C5rank": lambda: synth.genotype_fitness_normal(25_000, 8, 626, 45)}[os.environ.get("CFG", "C2")]()
+      "C5rank": lambda: synth.genotype_fitness_normal(25_000, 8, 626, 45),
+      # all of config 5 on ONE GPU: k_stream -- whose G pass takes eps from the kept sample, (z - mu) / softplus(omega), instead of a second draw
+      "C5": lambda: synth.genotype_fitness_normal(200_000, 8, 5_000, 45)}[os.environ.get("CFG", "C2")]()
 sp = port.spec_from_workload(wl)
 t0 = time.perf_counter()
 with bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, env_idx=wl.env_idx, geno_idx=wl.geno_idx, seed=42) as e:
