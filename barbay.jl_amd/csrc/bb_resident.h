@@ -899,9 +899,13 @@ BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, cons
     BB_PASS(cx, tid) { if (tid == 0) bb_set_word(S.rdy + 32 * cx.block, epoch); }
 }
 
+template <int KIND, int P, int TT> BB_DEV void br_theta_pre(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* stv, int buf);
 template <int KIND, int P, bool TG = false, bool MS = false>
 BB_DEV void br_moments(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, int buf, unsigned epoch, bool want_el = false) {
     double* lds = cx.lds;
+    // (genotype / replicate model: the units' terms of d/dtheta, by their theta_tilde threads -- idle in this pass -- in front of barrier 2, so
+    //  that the theta threads can add them up in the exchange's shadow: br_theta_pre, br_theta_sum)
+    if (KIND == 2) br_theta_pre<KIND, P, 0>(cx, M, Y, stv, buf);
     if (MS && want_el) {
         // the threads' ELBO terms: summed per wave (DPP rows, then the four rows in order), one partial per wave in LDS; the row
         // pass below adds the waves in order -> row entry K - 2
@@ -1124,7 +1128,7 @@ BB_DEV void br_grad_pre(BBCtx& cx, const BRLay& Y, BRSt<P>* stv, int buf) {
 #define BR_TH_PRE3 1
 #endif
 template <int KIND> BB_DEV constexpr bool br_th_pre() { return (KIND == 2 && BR_TH_PRE) || (KIND == 3 && BR_TH_PRE3); }
-template <int KIND, int P, int TT = 0>
+template <int KIND, int P, int TT>
 BB_DEV void br_theta_pre(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* stv, int buf) {
     if (!br_th_pre<KIND>()) return;
     double* lds = cx.lds;
@@ -1150,6 +1154,45 @@ BB_DEV void br_theta_pre(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* 
                 const double* zr = zbuf + bl * (T + 1);
                 *(bb_d2*)(lds + Y.gas + 2 * j) = bb_d2{wv * ((zr[T - 1] - zr[0]) - (double)(T - 1) * sv), wv};
             }
+        }
+    }
+}
+
+// ... and the theta threads add their members' entries up IN THE EXCHANGE'S SHADOW (BR_TH_SUM_F = 1): the entries are written during the M
+// pass (the theta_tilde threads are idle there) and visible since barrier 2; the sums wait in two register pairs (gp, lam: a theta pair
+// uses neither).  0: at the start of the G pass (C5's rank shape: S 13.7 k cycles -- the tile waits for that chain at barrier 1).
+// (Beside the F pass instead -- entries written in the shadow, summed behind the consume's barrier: F 1.5 k -> 3.3 k cycles, 12.77 -> 11.9 us.)
+#ifndef BR_TH_SUM_F
+#define BR_TH_SUM_F 1
+#endif
+template <int KIND, int P>
+BB_DEV void br_theta_sum(BBCtx& cx, const DevModel& M, const BRLay& Y, BRSt<P>* stv) {
+    if (!(KIND == 2 && BR_TH_PRE && BR_TH_SUM_F)) return;
+    const double* lds = cx.lds;
+    BB_PASS(cx, tid) {
+        BRSt<P>& st = BB_PSTATE(stv, tid);
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int meta = st.meta[k];
+            if ((meta & 15) != SK_TH_R || !(meta & BRM_VALID)) continue;
+            bb_d2 sa{0.0, 0.0}, sw{0.0, 0.0};
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                if (!(meta & (x ? BRM_A1 : BRM_A0))) continue;
+                const int first = st.uo[k][x] & 0xffff, n = st.uo[k][x] >> 16;
+                const bb_d2* ge = (const bb_d2*)(lds + Y.gas) + first;
+                double a = 0.0, w = 0.0;
+                int i = 0;
+                for (; i + 4 <= n; i += 4) {          // (four 16-byte entries in flight per LDS round trip)
+                    const bb_d2 e0 = ge[i], e1 = ge[i + 1], e2 = ge[i + 2], e3 = ge[i + 3];
+                    a += (e0.x + e1.x) + (e2.x + e3.x);
+                    w += (e0.y + e1.y) + (e2.y + e3.y);
+                }
+                for (; i < n; ++i) { a += ge[i].x; w += ge[i].y; }
+                if (x) { sa.y = a; sw.y = w; } else { sa.x = a; sw.x = w; }
+            }
+            st.gp[k] = sa;
+            st.lam[k] = sw;
         }
     }
 }
@@ -1239,7 +1282,8 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                     if (!(x ? a1 : a0)) continue;
                     double acc = 0.0;
                     const int first = st.uo[k][x] & 0xffff, n = st.uo[k][x] >> 16;
-                    if (BR_TH_PRE) {          // (br_theta_pre: the members' terms w [..] and w, left in LDS before the exchange's barriers)
+                    if (BR_TH_PRE && BR_TH_SUM_F) acc = (x ? st.gp[k].y : st.gp[k].x) - (x ? st.lam[k].y : st.lam[k].x) * csum;          // (br_theta_sum, beside the F pass)
+                    else if (BR_TH_PRE) {          // (br_theta_pre: the members' terms w [..] and w, left in LDS before the exchange's barriers)
                         // (four 16-byte entries in flight per round trip: one after the other the ~40 members of a genotype are 40 LDS
                         //  round trips, 5 k cycles, that the whole tile waits for at the next barrier)
                         const bb_d2* ge = (const bb_d2*)(lds + Y.gas) + first;
@@ -1301,6 +1345,9 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
                         const double* zr = zbuf + (KIND <= 1 ? Y.zr0[0] : rt[1]) + bl * (T + 1);
                         double As = 0.0, Qs = 0.0;
                         int nn = 0;
+                        // (Measured and dropped, round 4: d/ds_bc from the telescoped sum As = (z_{T-1} - z_0) - (T - 1) s - sum_t c_t -- two reads of
+                        //  the barcode's row instead of T for the s_bc threads: the unit waves stay the last to leave the G pass, C2 11.87 -> 12.06 us,
+                        //  profiles/r04d_c2_experiments)
                         if (TT) {
                             double zrow[TT ? TT : 1];
 #pragma unroll
@@ -1416,7 +1463,10 @@ BB_DEV void br_xchg_publish(BBCtx& cx, const DevModel& M, const DevState& S, con
     // tile's 32 KB) and loads return in order, so it must be out of the way before this wave polls and reads the group rows
     if (A.pf == 0 && prefetch) br_prefetch_slot<P, HD>(cx, M, S, A, Y, stv, slot);
     br_grad_pre<KIND, P, AP>(cx, Y, stv, (int)(xc & 1));          // what of this step's gradient needs no totals
-    br_theta_pre<KIND, P>(cx, M, Y, stv, (int)(xc & 1));          // (genotype model: the theta threads' sums over their members)
+    br_theta_sum<KIND, P>(cx, M, Y, stv);          // (genotype model: the theta threads add their members' terms up -- left in front of barrier 2)
+    // (replicate model: theta adds R entries at the start of the G pass; its units' terms are formed HERE -- in the M pass they cost C3 more
+    //  than they save: M 2.0 k -> 2.9 k cycles, 17.1 -> 17.5 us)
+    if (KIND == 3) br_theta_pre<KIND, P, 0>(cx, M, Y, stv, (int)(xc & 1));
     br_draw_ahead<KIND, P, AP>(cx, A, Y, stv, next_step, next_stream);         // the next normals, in the shadow of the rows' flight
 }
 template <bool XG>
