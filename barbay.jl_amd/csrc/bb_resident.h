@@ -45,6 +45,16 @@
 #define BR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 #define BR_MAXT 16
+// BR_UNIT_PRIO: waves that hold unit pairs (s_bc, logsigma_bc, theta ...) raise their issue priority for the G pass (1) or for the G and the
+// following S pass (2).  Their G work is a chain of LDS round trips (a barcode's row per latent) that the SIMD's arbiter -- oldest wave first,
+// and they are the tile's youngest -- lets run only after the loglambda waves are done: they leave G last by far (per_wave_stamps.txt:
+// 8.3 k cycles against 3.4 - 5.5 k) and everybody waits for them at barrier 1.
+#ifndef BR_UNIT_PRIO
+#define BR_UNIT_PRIO 1
+#endif
+#ifndef BR_UNIT_PRIO_LEVEL
+#define BR_UNIT_PRIO_LEVEL 3
+#endif
 
 // (the prior of the segment's block travels with it: read per latent in the G pass, it must come from LDS -- fetched through the
 // model descriptor with a per-lane block index it was a chain of five dependent global loads per pair and step)
@@ -804,6 +814,9 @@ BB_DEV void br_sample(BBCtx& cx, const DevModel& M, const DevState& S, const Run
         }
     }
     BB_STAMP_WAVE(cx, S, A, 0);
+#ifndef BB_EMU
+    if (BR_UNIT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+#endif
     BB_SYNC(cx);                     // barrier 1: neighbours' z and the unit stages are visible
     BB_STAMP(cx, S, 21);
 }
@@ -1248,6 +1261,14 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     //  two numbers per unit through LDS, one more barrier -- so that the unit threads need not walk the barcode's row: the G pass
     //  is bound by the SIMDs' total VALU work, not by the unit waves; C2 15.3 -> 15.5 us per step, C3 unchanged.)
     BB_STAMP_WAVE(cx, S, A, 2);
+#ifndef BB_EMU
+    if (BR_UNIT_PRIO) {
+        bool u = false;
+#pragma unroll
+        for (int k = 0; k < P; ++k) u = u || ((stv->meta[k] & BRM_VALID) && (stv->meta[k] & 15) != SK_L);
+        if (__builtin_amdgcn_ballot_w64(u) != 0ull) __builtin_amdgcn_s_setprio(BR_UNIT_PRIO_LEVEL);
+    }
+#endif
     const double* zbuf = lds + Y.zl + buf * Y.NBT;
     // Genotype model: two passes.  Pass 0 updates everything but theta, and the theta_tilde thread of every mutant leaves w As in
     // LDS; after one more barrier the theta threads add up their genotypes' members (consecutive units of this tile) and update.
@@ -1423,6 +1444,9 @@ BB_DEV void br_update(BBCtx& cx, const DevModel& M, const DevState& S, const Run
     }
     // (the same thread has just read its entries of the slot buffer: its LDS-DMA of the next step's slot may overwrite them)
     if (A.pf == 2) br_prefetch_slot<P, HD>(cx, M, S, A, Y, stv, wslot.slot + 1 == A.W ? 0 : wslot.slot + 1);
+#ifndef BB_EMU
+    if (BR_UNIT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+#endif
     BB_STAMP_WAVE(cx, S, A, 3);
     BB_STAMP(cx, S, 28);
 }
