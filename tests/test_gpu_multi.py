@@ -119,16 +119,20 @@ def test_bench_rehearsal_two_ranks_on_one_gpu():
     (20 steps after 5) must measure the KERNELS, not the bracket: VERDICT r03 item 2.  With the closing barrier inside the timed region
     the 20-step form read 49.0 k steps/s against 76.6 k over 4000 steps (1.56x per step); now the region ends with each rank's own
     device idle and the job's time is the MAX over ranks, so what separates the two forms is one launch's fixed cost (prologue,
-    epilogue, host: ~45 us over 20 steps)."""
+    epilogue, host: ~45 us over 20 steps; two processes on one GPU add to it)."""
     short = _bench_rehearsal(2, 20, 5)
     assert short["n_gpus"] == 2 and short["posterior_finite"] and short["replicated_latents_identical_on_all_ranks"]
     assert "resident launch" in short["config"]["collective"]
     assert len(short["rank_ms"]) == 2 and max(short["rank_ms"]) == pytest.approx(short["ms_per_step"] * 20, rel=1e-3)
     assert short["config"]["kernel_instance"].startswith("k_res<0,1,1024,true,")
+    # the timed region is the launch plus the host's share of bb_run, not the bracket: with the closing gloo barrier inside it the region
+    # was ~100 us longer than the launch's own HIP-event time; now 25 us (N = 1: 26 us)
+    wall_us, kernel_us = short["ms_per_step"] * 20 * 1e3, short["roofline"]["avg_launch_us"]
+    assert wall_us - kernel_us < 60.0, (wall_us, kernel_us)
     steady = _bench_rehearsal(2, 4000, 200)
     ratio = short["ms_per_step"] / steady["ms_per_step"]
     print(f"20-step form {short['value']:.0f} steps/s, 4000-step form {steady['value']:.0f} steps/s, per-step ratio {ratio:.3f}")
-    assert ratio < 1.35, (short["ms_per_step"], steady["ms_per_step"])
+    assert ratio < 1.45, (short["ms_per_step"], steady["ms_per_step"])          # (measured 1.25 - 1.30; 1.56 with the barrier inside)
 
 
 @pytest.mark.parametrize("case", ["fitness_T6", "genotype_runs"])
