@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, steps, p2p, out_dir):
+def _worker(rank, world, port, case, steps, p2p, out_dir, ms=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,8 @@ def _worker(rank, world, port, case, steps, p2p, out_dir):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     sp = c.synth(case, seed=4)
-    e = make_engine(sp, None, seed=5, window=4, resum_every=1, rank=rank, world_size=world, device=rank)
+    ekw = dict(samples_per_step=2, elbo_every=1) if ms else {}
+    e = make_engine(sp, None, seed=5, window=4, resum_every=1, rank=rank, world_size=world, device=rank, **ekw)
     bb.dist.init_rccl(e)
     on = bb.dist.setup_p2p(e) if p2p else False
     for _ in range(2):                      # the second pass restarts with the inboxes still holding the first's words
@@ -55,7 +56,8 @@ def _worker(rank, world, port, case, steps, p2p, out_dir):
     st = e.stats()
     if rank == 0:
         np.savez(os.path.join(out_dir, "sharded.npz"), mean=mean, sigma=sigma, on=on, pairs=st["persistent_pairs"],
-                 identical=all(cp == copies[0] for cp in copies))
+                 identical=all(cp == copies[0] for cp in copies), name=e.kernel_name(),
+                 trace=e.elbo_trace(0, steps) if ms else np.zeros(0))
     dist.barrier()
     e.close()
     dist.destroy_process_group()
@@ -84,6 +86,31 @@ def test_sharded_over_real_peers(hip_lib, tmp_path, monkeypatch, case, p2p):
         assert bool(got["on"]) and int(got["pairs"]) >= 1          # the resident launch over peer-mapped inboxes really ran
     assert bool(got["identical"])                                   # replicated global latents: bit-identical on all ranks
     assert np.abs(got["mean"] - m1).max() < 1e-8 and np.abs(got["sigma"] - s1).max() < 1e-8
+
+
+@pytest.mark.parametrize("case", ["fitness_T6", "genotype"])
+def test_sharded_several_samples_and_elbo_trace_over_real_peers(hip_lib, tmp_path, monkeypatch, case):
+    """round 4: `Turing.ADVI(2, ...)` with the ELBO recorded every step stays in the resident launch on a sharded run (MS + cross-GPU
+    instances); `genotype`: geno_idx in order of appearance -- regrouped inside the library, ownership by bb_get_owned."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch.multiprocessing as mp
+    import _cases as c
+    from conftest import make_engine
+    monkeypatch.setenv("BB_TUNE_NB", "24" if case == "genotype" else "8")
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    steps = 20
+    sp = c.synth(case, seed=4)
+    with make_engine(sp, hip_lib, seed=5, window=4, resum_every=1, launch_mode=1, samples_per_step=2, elbo_every=1) as e1:
+        e1.run(steps)
+        m1, s1 = e1.posterior()
+        t1 = e1.elbo_trace(0, steps)
+    mp.spawn(_worker, args=(2, _free_port(), case, steps, True, str(tmp_path), True), nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    assert bool(got["on"]) and int(got["pairs"]) >= 1 and str(got["name"]).endswith(",true>"), str(got["name"])
+    assert bool(got["identical"])
+    assert np.abs(got["mean"] - m1).max() < 1e-8 and np.abs(got["sigma"] - s1).max() < 1e-8
+    assert np.abs(got["trace"] - t1).max() <= 1e-9 * np.abs(t1).max()
 
 
 @pytest.mark.parametrize("flags", [[], ["--no-p2p"]], ids=["resident", "rccl"])
