@@ -431,6 +431,7 @@ static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
 // bb_create -> create_inner (and the shards of a multi-device handle): lay the loglambda block out in FRONT of the per-genotype / per-mutant
 // blocks (the handle's internal order; the caller's stays the reference's source order) -- see bb_create
 static thread_local bool g_loglambda_first = false;
+static int ensure_scratch(bb_handle* h);
 static void owned_ranges(const bb_handle* sh, std::vector<std::pair<long long, long long>>& out);
 static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, bool apply, bool with_elbo);
 static int theta_sync_local(bb_handle* const* hs, int n);
@@ -489,15 +490,16 @@ static bb_res_kernel res_kernel(int kind, int P, int nthr, bool xg, int T, bool 
 #endif
 
 #ifndef BB_EMU
-static bb_stream_kernel stream_kernel(int kind, int nthr, int T, const char** nm = nullptr) {
+static bb_stream_kernel stream_kernel(int kind, int nthr, int T, const char** nm = nullptr, bool ms = false) {
 #ifdef BB_FAST_BUILD
     if (nm) *nm = "(experiment build)";
+    if (ms) return nullptr;
     if (nthr == 1024 && kind == 0 && T == 8) return k_stream<0, 1024, 8>;
     if (nthr == 1024 && kind == 2 && T == 8) return k_stream<2, 1024, 8>;
     if (nthr == 1024 && kind == 3 && T == 6) return k_stream<3, 1024, 6>;
     return nullptr;
 #else
-    return bb_stream_instance(kind, nthr, T, nm);
+    return ms ? bb_stream_instance_ms(kind, nthr, T, nm) : bb_stream_instance(kind, nthr, T, nm);
 #endif
 }
 #endif
@@ -682,9 +684,9 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     if (force_stream || P > (h->nthr > 512 ? 2 : (h->nthr > 256 ? 3 : 4))) {
         const int T0 = uniform_T(h->M);
         const bool nostream = (ev = getenv("BB_NO_STREAM")) && atoi(ev) > 0;
-        // every replicate the same even T (instances: 4, 6, 8), flat-index-aligned pairs, one GPU, one sample per step, no ELBO trace
-        stream = !nostream && !br_any_parity(h->M) && (T0 == 8 || T0 == 6 || T0 == 4) && h->nthr % 64 == 0 &&
-                 !h->p2p_on && h->o.samples_per_step == 1 && h->o.elbo_every == 0;
+        // every replicate the same even T (instances: 4, 6, 8), flat-index-aligned pairs, one GPU; several samples per step / the ELBO trace:
+        // the MS instances (T = 6, 8 at 1024 threads; tests: 512)
+        stream = !nostream && !br_any_parity(h->M) && (T0 == 8 || T0 == 6 || T0 == 4) && h->nthr % 64 == 0 && !h->p2p_on;
         if (stream) {          // (a barcode takes a power-of-two number of lanes there: T = 6 four)
             P = (int)((br_tile_span(h->M, NB, true, true) + h->nthr - 1) / h->nthr);
             if (P > 64) stream = false;
@@ -704,7 +706,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     if ((size_t)Y.total * 8 > 160 * 1024) return false;
 #ifndef BB_EMU
     const bool ms = h->o.samples_per_step != 1 || h->o.elbo_every != 0;
-    const void* k = stream ? (const void*)stream_kernel(h->M.kind, h->nthr, uniform_T(h->M))
+    const void* k = stream ? (const void*)stream_kernel(h->M.kind, h->nthr, uniform_T(h->M), nullptr, ms)
                            : (const void*)res_kernel(h->M.kind, P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), ms);
     if (!k) return false;
     const int lds = Y.total * 8;
@@ -727,6 +729,7 @@ static bool try_resident(bb_handle* h, bool any_parity) {
     h->res_nblk = nblk;
     h->res_pf = pf;
     h->res_stream = stream;
+    if (stream && h->o.samples_per_step > 1 && ensure_scratch(h)) { h->res_P = 0; return false; }      // (the samples' gradient sums live in gacc_mu / gacc_om)
     h->lds_doubles_p = (size_t)Y.total;
     if (!host_tables(h, tb, tg)) { h->res_P = 0; return false; }
     return true;
@@ -899,14 +902,22 @@ static void emu_res_phase(EmuPersist& E, int phase, long long it, long long nste
     }
 }
 
-template <int KIND, int TT>
+template <int KIND, int TT, bool MS>
 static void emu_stream_phase(EmuPersist& E, int phase, long long it, long long nsteps) {
     bb_handle* h = E.h;
     const RunArgs& A = E.A;
     BSG* gs = (BSG*)E.st.data();
     auto cxof = [&](int b) { return BBCtx{h->nthr, b, E.lds.data() + (size_t)b * (h->lds_doubles_p + 64), nullptr}; };
     const BRLay& Y = h->Yh;
-    const unsigned long long step = (unsigned long long)(h->step + it);
+    // `it` counts the exchanges of this run: step (h->step + it / NS), sample it % NS (as emu_res_phase)
+    const int NS = MS ? (A.S < 1 ? 1 : A.S) : 1;
+    const unsigned long long step = (unsigned long long)(h->step + it / NS);
+    const int smp = (int)(it % NS);
+    const unsigned long long xc = step * (unsigned long long)NS + (unsigned long long)smp;
+    auto rec = [&](unsigned long long st_) { return MS && A.elbo_every > 0 && st_ % (unsigned long long)A.elbo_every == 0; };
+    const bool want_el = rec(step);
+    const int ring = A.elbo_every > 0 ? (int)((step / (unsigned long long)A.elbo_every) % BB_ELBO_RING) : 0;
+    const BSMs ms = MS ? bs_ms_of(A, step, smp, NS, want_el, rec(step + 1)) : bs_ms_plain((unsigned)step);
     BRSt<1>* nost = nullptr;
     for (int b = 0; b < (phase == 2 ? bbp_groups(A) : h->res_nblk); ++b) {
         BBCtx cx = cxof(b);
@@ -915,16 +926,17 @@ static void emu_stream_phase(EmuPersist& E, int phase, long long it, long long n
         if (phase == 0) {
             br_tile_setup<KIND>(cx, h->M, h->S, A, Y, h->res_NB, KIND <= 2 ? h->nthr / 16 : h->nthr / 64);
             *bad_any = 0;
-            bs_sample0<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)h->step, gb);      // (the launch's first sample; later ones: inside the G passes)
+            // (the launch's first sample; later ones: inside the G passes)
+            bs_sample0<KIND, TT, MS>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)h->step, gb, (int)(((unsigned long long)h->step * (unsigned long long)NS) & 1ull), rec((unsigned long long)h->step));
         } else if (phase == 1) {
-            bs_moments<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, gb);
-            br_row_publish<1, true, false>(cx, h->M, h->S, Y, nost, A.xepoch0 + (unsigned)(step + 1));
+            bs_moments<KIND, TT, MS>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, gb, ms.buf, want_el);
+            br_row_publish<1, true, MS>(cx, h->M, h->S, Y, nost, A.xepoch0 + (unsigned)(xc + 1), want_el);
         } else if (phase == 2) {
-            br_xchg_lead<false>(cx, h->M, h->S, A, Y, step, &E.ok);
+            br_xchg_lead<false>(cx, h->M, h->S, A, Y, xc, &E.ok);
         } else if (phase == 3) {
-            br_xchg_consume<KIND, 1, false, false>(cx, h->M, h->S, A, Y, nost, step, &E.ok);
-            bs_update_l<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any, gb);
-            bs_update_u<KIND, TT>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any, gb);
+            br_xchg_consume<KIND, 1, false, MS>(cx, h->M, h->S, A, Y, nost, xc, &E.ok, want_el, ring, smp);
+            bs_update_l<KIND, TT, MS>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any, gb, ms);
+            bs_update_u<KIND, TT, MS>(cx, h->M, h->S, A, Y, h->res_NB, h->res_P, (unsigned)step, bb_slot_of(A, step), bad_any, gb, ms);
         } else {
             if (*bad_any) h->S.hstatus[1] = 1u;
             if (b == 0) { h->S.ctr[0] = (unsigned long long)(h->step + nsteps); h->S.ctr[1] = h->S.ctr[0]; }
@@ -937,9 +949,10 @@ static void emu_persist_dispatch(EmuPersist& E, int phase, long long it, long lo
         const int T = uniform_T(E.h->M);
         auto byT = [&](auto kindc) {
             constexpr int KIND = decltype(kindc)::value;
-            if (T == 8) emu_stream_phase<KIND, 8>(E, phase, it, nsteps);
-            else if (T == 6) emu_stream_phase<KIND, 6>(E, phase, it, nsteps);
-            else emu_stream_phase<KIND, 4>(E, phase, it, nsteps);
+            const bool ms = E.h->o.samples_per_step != 1 || E.h->o.elbo_every != 0;
+            if (T == 8) ms ? emu_stream_phase<KIND, 8, true>(E, phase, it, nsteps) : emu_stream_phase<KIND, 8, false>(E, phase, it, nsteps);
+            else if (T == 6) ms ? emu_stream_phase<KIND, 6, true>(E, phase, it, nsteps) : emu_stream_phase<KIND, 6, false>(E, phase, it, nsteps);
+            else ms ? emu_stream_phase<KIND, 4, true>(E, phase, it, nsteps) : emu_stream_phase<KIND, 4, false>(E, phase, it, nsteps);
         };
         switch (E.h->M.kind) {
         case 0: byT(std::integral_constant<int, 0>{}); break;
@@ -1049,7 +1062,7 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
-        if (h->res_stream) hipLaunchKernelGGL(stream_kernel(h->M.kind, h->nthr, uniform_T(h->M)), dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream,
+        if (h->res_stream) hipLaunchKernelGGL(stream_kernel(h->M.kind, h->nthr, uniform_T(h->M), nullptr, res_ms(h)), dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream,
                                               (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n, h->res_P);
         else if (kr) hipLaunchKernelGGL(kr, dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n);
         else hipLaunchKernelGGL(k, dim3(h->nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BBLds*)h->dL, A, h->NB, n);
@@ -2699,14 +2712,14 @@ extern "C" int bb_kernel_name(bb_handle* h, char* buf, int64_t len) {
     char tmp[96];
 #ifdef BB_EMU
     // (the emulation runs the block programs as host functions: it names the launch, the compile-time T / AP / MS are the product's)
-    if (h->res_P && h->res_stream) snprintf(tmp, sizeof tmp, "emu:k_stream<%d,%d,%d>", h->M.kind, h->nthr, uniform_T(h->M));
+    if (h->res_P && h->res_stream) snprintf(tmp, sizeof tmp, "emu:k_stream<%d,%d,%d%s>", h->M.kind, h->nthr, uniform_T(h->M), (h->o.samples_per_step != 1 || h->o.elbo_every != 0) ? ",true" : "");
     else if (h->res_P) snprintf(tmp, sizeof tmp, "emu:k_res<%d,%d,%d,%s,*,%s,%s>", h->M.kind, h->res_P, h->nthr, h->p2p_on ? "true" : "false",
                                 br_any_parity(h->M) ? "true" : "false", (h->o.samples_per_step != 1 || h->o.elbo_every != 0) ? "true" : "false");
     else if (h->persist_P) snprintf(tmp, sizeof tmp, "emu:k_persist<%d,%d,%d>", h->M.kind, h->persist_P, h->nthr);
     else snprintf(tmp, sizeof tmp, "emu:k_sample + k_update");
     nm = tmp;
 #else
-    if (h->res_P && h->res_stream) (void)stream_kernel(h->M.kind, h->nthr, uniform_T(h->M), &nm);
+    if (h->res_P && h->res_stream) (void)stream_kernel(h->M.kind, h->nthr, uniform_T(h->M), &nm, res_ms(h));
     else if (h->res_P) (void)res_kernel(h->M.kind, h->res_P, h->nthr, h->p2p_on, uniform_T(h->M), br_any_parity(h->M), res_ms(h), &nm);
     else if (h->persist_P) (void)persist_kernel(h->M.kind, h->persist_P, h->nthr, h->p2p_on, &nm);
     else { snprintf(tmp, sizeof tmp, "k_sample<%d> + k_update<%d>", h->M.kind, h->M.kind); nm = tmp; }

@@ -20,4 +20,6 @@ BB_INST bb_res_kernel bb_res_instance_k3(int P, int nthr, bool xg, int T, bool a
 BB_INST bb_res_kernel bb_res_instance_k4(int P, int nthr, bool xg, int T, bool ap, bool ms, const char** nm = nullptr);
 // k_stream<KIND, NT, TT>: all five kinds, 1024 or 512 threads, T = 8, 6 or 4 (every replicate the same)
 BB_INST bb_stream_kernel bb_stream_instance(int kind, int nthr, int T, const char** nm = nullptr);
+// ... their MS form (several MC samples per step and / or the ELBO trace): k_stream<KIND, NT, TT, true>, T = 8 or 6
+BB_INST bb_stream_kernel bb_stream_instance_ms(int kind, int nthr, int T, const char** nm = nullptr);
 #endif

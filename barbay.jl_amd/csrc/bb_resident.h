@@ -857,7 +857,8 @@ BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, cons
             double e = 0.0;
             if (want_el) {
 #ifdef BB_EMU
-                for (int t2 = 0; t2 < cx.nthr; ++t2) e += BB_PSTATE(stv, t2).el;
+                if (stv) for (int t2 = 0; t2 < cx.nthr; ++t2) e += BB_PSTATE(stv, t2).el;
+                else for (int w = 0; w < (cx.nthr + 63) / 64; ++w) e += lds[Y.L.part + w];          // (k_stream: no register state; bs_moments left the sums)
 #else
                 for (int w = 0; w < (cx.nthr >> 6); ++w) e += lds[Y.L.part + w];
 #endif

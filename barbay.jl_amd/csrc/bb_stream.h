@@ -54,6 +54,7 @@ struct BSG {
     double rm, rn, wm;                // loglambda, mutant: residuals of the pair's two forward differences; precision of the unit of the first
     double xa, xq;                    // ... and what of them goes to the unit sums being formed (one environment at a time)
     double lam0, lam1;                // running sums of lambda over the thread's loglambda slots: the NEXT step's S_t contributions
+    double el;                        // MS: the thread's ELBO terms of the sample it formed last (summed over its slots; the M pass reduces them)
     double cv[BR_NCV];                // M pass: the thread's moment contributions
     int ok;                           // slot holds a pair of the kind the pass handles
 };
@@ -64,16 +65,26 @@ static inline
 #else
 __device__ __attribute__((noinline))
 #endif
-bb_d2 bs_draw(unsigned long long seed, long long i0, unsigned step) {
+bb_d2 bs_draw(unsigned long long seed, long long i0, unsigned step, unsigned stream = 0u) {
     double a, b;
-    bb_normal_pair(seed, (unsigned long long)(i0 >> 1), step, 0u, &a, &b);
+    bb_normal_pair(seed, (unsigned long long)(i0 >> 1), step, stream, &a, &b);
     return bb_d2{a, b};
 }
-BB_DEV bb_d2 bs_draw_inline(unsigned long long seed, long long i0, unsigned step) {
+BB_DEV bb_d2 bs_draw_inline(unsigned long long seed, long long i0, unsigned step, unsigned stream = 0u) {
     double a, b;
-    bb_normal_pair(seed, (unsigned long long)(i0 >> 1), step, 0u, &a, &b);
+    bb_normal_pair(seed, (unsigned long long)(i0 >> 1), step, stream, &a, &b);
     return bb_d2{a, b};
 }
+// MS instances (several MC samples per step -- Turing.ADVI(samples_per_step, ..), src/vi.jl:98 -- and / or the ELBO trace): what changes
+// from sample to sample, all wave-uniform.  Sample s of a step is exchange xc = step NS + s: its parity picks the stage-table / row
+// buffers; its gradient joins running sums in memory (DevState.gacc_*: first sample stores, later ones add, the last one averages, adds
+// the entropy term and updates); the sample formed at the end of its G passes is (step, stream s + 1), or (step + 1, stream 0) after the last.
+struct BSMs {
+    int NS, smp, buf;
+    bool last, el_next;          // the sample that updates; the NEXT sample (formed in this G pass) records its ELBO terms
+    unsigned nstep, nstream;     // step and stream of the next sample's draw
+};
+BB_DEV BSMs bs_ms_plain(unsigned step) { return BSMs{1, 0, (int)(step & 1u), true, false, step + 1u, 0u}; }
 // (inline in the G pass: the pair's state loads stay in flight behind it -- a call drains them first; C5 93.1 -> 91.4 us, round 3)
 #ifndef BS_G_INLINE_DRAW
 #define BS_G_INLINE_DRAW 1
@@ -259,9 +270,40 @@ BB_DEV void bs_put_u(double* lds, const DevModel& M, const BRLay& Y, const RunAr
     }
 }
 
-// ---- the launch's first sample (every later one is formed inside the G passes of the step before it) -------------------------------
+// MS: ELBO terms of a freshly formed sample of a pair (the split of br_sample's MS form): per latent -(z - m)^2 / (2 v^2) + log sigma, per
+// (b, t) R z - lambda, per unit - logsigma_eff x (time steps that use it)
 template <int KIND, int TT>
-BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv) {
+BB_DEV double bs_el_pair(const double* lds, const DevModel& M, const BRLay& Y, const RunArgs& A, const BRSt<1>& st, const bb_d2 z, const bb_d2 sp) {
+    const int meta = st.meta[0], kd = meta & 15;
+    if (!(meta & BRM_VALID) || !(kd < SK_GS || A.count_globals)) return 0.0;          // (sharded run: rank 0 counts the replicated blocks)
+    const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
+    double pm0, iv0, pm1, iv1, el = 0.0;
+    br_pair_prior<KIND>(lds, Y, st, 0, a0, a1, &pm0, &iv0, &pm1, &iv1);
+    if (a0) el += -0.5 * (z.x - pm0) * (z.x - pm0) * iv0 + bb_log(sp.x);
+    if (a1) el += -0.5 * (z.y - pm1) * (z.y - pm1) * iv1 + bb_log(sp.y);
+    if (kd == SK_L) {
+        el += (double)st.cnt[0][0] * z.x - bb_exp(z.x);
+        el += (double)st.cnt[0][1] * z.y - bb_exp(z.y);
+    } else if (kd == SK_LS_E || (KIND >= 2 && kd == SK_LS_R)) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            if (!(x ? a1 : a0)) continue;
+            int n = TT - 1;
+            if (KIND == 1 || KIND == 4) {
+                const int* envt = (const int*)(lds + Y.envt);
+                const int e_ = (st.uo[0][2] >> (8 * x)) & 255, tc = KIND == 4 ? ((const int*)(lds + Y.rtab))[4 * st.pt[0]] : 0;
+                n = 0;
+                for (int tt = 0; tt < TT - 1; ++tt) n += envt[tc + tt + 1] == e_ ? 1 : 0;
+            }
+            el -= (x ? z.y : z.x) * (double)n;
+        }
+    }
+    return el;
+}
+
+// ---- the launch's first sample (every later one is formed inside the G passes of the step before it) -------------------------------
+template <int KIND, int TT, bool MS = false>
+BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv, int buf0 = -1, bool want_el = false) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
@@ -270,11 +312,11 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
     const int nseg = ((const int*)(lds + L.misc))[0];
     const int lspan = bs_lspan(sg, nseg);
     BB_STAMP(cx, S, 20);
-    BB_PASS(cx, tid) { BSG& g = BB_PSTATE(gv, tid); g.lam0 = g.lam1 = 0.0; }
+    BB_PASS(cx, tid) { BSG& g = BB_PSTATE(gv, tid); g.lam0 = g.lam1 = 0.0; g.el = 0.0; }
     for (int k = 0; k < P; ++k) {
         BB_PASS(cx, tid) {
             BSG& g = BB_PSTATE(gv, tid);
-            if (tid + k * cx.nthr < lspan) bs_desc_l<KIND, TT, false>(M, Y, t, sg, tid + k * cx.nthr, g.st, lds);
+            if (tid + k * cx.nthr < lspan) bs_desc_l<KIND, TT, MS>(M, Y, t, sg, tid + k * cx.nthr, g.st, lds);
             else br_desc<KIND, 1, false, bs_lpb<TT>(), false>(M, Y, t, sg, nseg, g0, g1, tid + k * cx.nthr, g.st, 0, lds);
             const int meta = g.st.meta[0];
             g.z = bb_d2{0.0, 0.0};
@@ -282,6 +324,7 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
                 const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
                 const bb_d2 mu = br_load_pair<false>(S.mu, g.st.i0[0], a0, a1), om = br_load_pair<false>(S.om, g.st.i0[0], a0, a1);
                 g.z = bs_z(mu, om, bs_draw(A.seed, g.st.i0[0], step), &g.sp, &g.sg);
+                if (MS && want_el) g.el += bs_el_pair<KIND, TT>(lds, M, Y, A, g.st, g.z, g.sp);
             }
         }
         BB_PASS(cx, tid) {
@@ -289,7 +332,7 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
             const double zn = BS_NEXT(gv, tid, z.x);
             const int p = tid + k * cx.nthr, meta = g.st.meta[0];
             if (p < lspan) { if ((meta & 15) == SK_L) bs_put_l<KIND>(lds, Y, g.st.zoff[0], meta, g.z, zn, g); }
-            else bs_put_u<KIND>(lds, M, Y, A, g.st, (int)(step & 1u), g.z);
+            else bs_put_u<KIND>(lds, M, Y, A, g.st, buf0 >= 0 ? buf0 : (int)(step & 1u), g.z);
         }
     }
     BB_SYNC(cx);
@@ -297,17 +340,34 @@ BB_DEV void bs_sample0(BBCtx& cx, const DevModel& M, const DevState& S, const Ru
 }
 
 // ---- M: the loglambda pairs' moment contributions, summed per thread, then by class over the wave, one LDS entry per (wave, class, value) ----
-template <int KIND, int TT>
-BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv) {
+template <int KIND, int TT, bool MS = false>
+BB_DEV void bs_moments(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, BSG* gv, int buf_ = -1, bool want_el = false) {
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
     constexpr int LPB = bs_lpb<TT>();
-    const int buf = (int)(step & 1u), lspan = bs_lspan(sg, nseg);
+    const int buf = buf_ >= 0 ? buf_ : (int)(step & 1u), lspan = bs_lspan(sg, nseg);
     const int R = KIND <= 2 ? 1 : M.R;
     BB_STAMP(cx, S, 22);
+    if (MS) {
+        // the threads' ELBO terms of this sample (gathered when it was formed): one partial per wave, br_row_publish adds them in order
+        BB_PASS(cx, tid) {
+            BSG& g = BB_PSTATE(gv, tid);
+#ifdef BB_EMU
+            if (tid == 0) { double e = 0.0; if (want_el) for (int t2 = 0; t2 < cx.nthr; ++t2) e += BB_PSTATE(gv, t2).el; lds[L.part] = e; for (int w = 1; w < (cx.nthr + 63) / 64; ++w) lds[L.part + w] = 0.0; }
+#else
+            double e = br_row16_sum(want_el ? g.el : 0.0);
+            const int lo_ = __double2loint(e), hi_ = __double2hiint(e);
+            double w_ = 0.0;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) w_ += __hiloint2double(__builtin_amdgcn_readlane(hi_, 16 * r4), __builtin_amdgcn_readlane(lo_, 16 * r4));
+            if ((tid & 63) == 0) lds[L.part + (tid >> 6)] = w_;
+#endif
+        }
+        BB_PASS(cx, tid) { BB_PSTATE(gv, tid).el = 0.0; }
+    }
     // (several replicates: a thread's slots may sit in different replicates' segments -- one round per replicate; the DPP sums need whole
     //  waves, so every thread takes every round)
     for (int r = 0; r < R; ++r) {
@@ -414,9 +474,56 @@ BB_DEV bool bs_apply_store(const DevModel& M, const DevState& S, const RunArgs& 
     return !(chk - chk == 0.0);
 }
 
+// MS, NS > 1: sample smp's gradient of the pair (likelihood + prior part gl, and gl a for omega) joins the running sums in memory; the last
+// sample averages them, adds the entropy term and takes the optimiser step (bb_update_pair's arithmetic).  Returns "non-finite".
+template <bool MS>
+BB_DEV bool bs_finish_pair(const DevModel& M, const DevState& S, const RunArgs& A, const BBSlot wslot, double* hs_m, double* hs_o,
+                           long long i0, long long ih, bool a0, bool a1, double gl0, double gl1, BSG& g, const BSMs& ms) {
+    if (!MS || ms.NS == 1) return bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, ih, a0, a1, gl0, gl1, g);
+    bb_d2 gm{gl0, gl1}, go{gl0 * g.a.x, gl1 * g.a.y};
+    if (ms.smp > 0) {
+        const bb_d2 pm = br_load_pair<false>(S.gacc_mu, i0, a0, a1), po = br_load_pair<false>(S.gacc_om, i0, a0, a1);
+        gm.x += pm.x; gm.y += pm.y; go.x += po.x; go.y += po.y;
+    }
+    if (!ms.last) {
+        br_store_pair<false>(S.gacc_mu, i0, a0, a1, gm);
+        br_store_pair<false>(S.gacc_om, i0, a0, a1, go);
+        return false;
+    }
+    const double invS = 1.0 / (double)ms.NS;
+    // (bs_apply_store forms go = fma(g, a, h): hand it g = the averaged gradient and a such that g a = the averaged omega part)
+    const double g0 = gm.x * invS, g1 = gm.y * invS;
+    const double go0 = go.x * invS + g.h.x, go1 = go.y * invS + g.h.y;
+    bb_d2 nhm = g.hm, nho = g.ho;
+    if (a0) {
+        bb_opt_apply(M, S, A, wslot, 0, ih, -g0, g.hm.x, &nhm.x, &g.mu.x, &g.am.x, &g.lo.x);
+        bb_opt_apply(M, S, A, wslot, 1, ih, -go0, g.ho.x, &nho.x, &g.om.x, &g.ao.x, &g.lo.y);
+    }
+    if (a1) {
+        bb_opt_apply(M, S, A, wslot, 0, ih + 1, -g1, g.hm.y, &nhm.y, &g.mu.y, &g.am.y, &g.lo.z);
+        bb_opt_apply(M, S, A, wslot, 1, ih + 1, -go1, g.ho.y, &nho.y, &g.om.y, &g.ao.y, &g.lo.w);
+    }
+    br_store_pair<false>(S.mu, i0, a0, a1, g.mu);
+    br_store_pair<false>(S.om, i0, a0, a1, g.om);
+    br_store_pair<false>(S.acc_mu, i0, a0, a1, g.am);
+    br_store_pair<false>(S.acc_om, i0, a0, a1, g.ao);
+    bb_store_lo(S, i0, a0, a1, g.lo);
+    if (hs_m) { br_store_pair_stream<false>(hs_m, ih, a0, a1, nhm); br_store_pair_stream<false>(hs_o, ih, a0, a1, nho); }
+    const double chk = (a0 ? g.mu.x + g.om.x : 0.0) + (a1 ? g.mu.y + g.om.y : 0.0);
+    return !(chk - chk == 0.0);
+}
+// (MS, a sample that does not update: only mu, omega are needed)
+BB_DEV void bs_load_mu_om(const DevState& S, long long i0, bool a0, bool a1, BSG& g) {
+    g.mu = br_load_pair<false>(S.mu, i0, a0, a1); g.om = br_load_pair<false>(S.om, i0, a0, a1);
+    g.am = g.ao = g.hm = g.ho = bb_d2{0, 0};
+    g.lo = bb_f4{0.f, 0.f, 0.f, 0.f};
+}
+
 // ---- G-L: every loglambda pair slot -- state in, the draw again, gradient, the barcode's unit sums, optimiser, out; the next sample ----
-template <int KIND, int TT>
-BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv) {
+template <int KIND, int TT, bool MS = false>
+BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv,
+                        const BSMs ms_ = BSMs{1, 0, -1, true, false, 0u, 0u}) {
+    const BSMs ms = (MS && ms_.buf >= 0) ? ms_ : bs_ms_plain(step);
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     constexpr int LPB = bs_lpb<TT>();
@@ -424,7 +531,7 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
     const int g0t = KIND == 2 ? S.tile_g[cx.block] : 0, g1t = KIND == 2 ? S.tile_g[cx.block + 1] : 0;
     const BRSeg* sg = (const BRSeg*)(lds + Y.seg);
     const int nseg = ((const int*)(lds + L.misc))[0];
-    const int lspan = bs_lspan(sg, nseg), buf = (int)(step & 1u);
+    const int lspan = bs_lspan(sg, nseg), buf = ms.buf;
     const int PL = (lspan + cx.nthr - 1) / cx.nthr;           // slots with loglambda pairs: the same for every thread (DPP needs whole waves)
     const int E = (KIND == 1 || KIND == 4) ? M.E : 1;
     double* hs_m = nullptr;
@@ -447,7 +554,8 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
                 if ((g.st.meta[0] & BRM_VALID) && (g.st.meta[0] & 15) == SK_L) {
                     g.ok = 1;
                     const long long i0 = g.st.i0[0];
-                    bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[g.st.meta[0] >> 12].pad, true, true, g);
+                    if (MS && !ms.last) bs_load_mu_om(S, i0, true, true, g);
+                    else bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[g.st.meta[0] >> 12].pad, true, true, g);
                     if (BS_ZKEEP) {
                         g.z = *(const bb_d2*)(lds + Y.zl + g.st.zoff[0]);
                         double sp0, sg0, sp1, sg1;
@@ -457,7 +565,7 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
                         g.a = bb_d2{(g.z.x - g.mu.x) * r0 * sg0, (g.z.y - g.mu.y) * r1 * sg1};          // eps = (z - mu) / softplus(omega)
                         g.h = bb_d2{sg0 * r0, sg1 * r1};
                     } else {
-                        g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
+                        g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step, (unsigned)ms.smp) : bs_draw(A.seed, i0, step, (unsigned)ms.smp);
                         g.z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);
                         g.a = bb_d2{g.e.x * g.sg.x, g.e.y * g.sg.y};
                         g.h = bb_d2{g.sg.x * bb_rcp(g.sp.x), g.sg.y * bb_rcp(g.sp.y)};
@@ -527,9 +635,10 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
             g.z = bb_d2{0.0, 0.0};
             if (g.ok) {
                 const long long i0 = g.st.i0[0];
-                if (bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, i0 - sg[g.st.meta[0] >> 12].pad, true, true, g.g0, g.g1, g)) *bad_any = 1;
-                const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
+                if (bs_finish_pair<MS>(M, S, A, wslot, hs_m, hs_o, i0, i0 - sg[g.st.meta[0] >> 12].pad, true, true, g.g0, g.g1, g, ms)) *bad_any = 1;
+                const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, ms.nstep, ms.nstream) : bs_draw(A.seed, i0, ms.nstep, ms.nstream);
                 g.z = bs_z(g.mu, g.om, en, &g.sp, &g.sg);
+                if (MS && ms.el_next) g.el += bs_el_pair<KIND, TT>(lds, M, Y, A, g.st, g.z, g.sp);
             }
         }
         BB_PASS(cx, tid) {
@@ -544,9 +653,9 @@ BB_DEV void bs_update_l(BBCtx& cx, const DevModel& M, const DevState& S, const R
 
 // ---- G-U: the unit pair slots (and the replicated global latents on tile 0) ----------------------------------------------------------
 // part A of a slot: state in, the step's draw again, the owner's own sample -- nothing of it needs the loglambda lanes' sums
-template <int KIND, int TT>
+template <int KIND, int TT, bool MS = false>
 BB_DEV bool bs_unit_a(const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, const BBTile& t, const BRSeg* sg, int nseg, int g0t, int g1t,
-                      const double* hs_m, const double* hs_o, int p, int lspan, unsigned step, double* lds, BSG& g) {
+                      const double* hs_m, const double* hs_o, int p, int lspan, unsigned step, double* lds, BSG& g, const BSMs& ms) {
     g.ok = 0;
     if (p < lspan) return false;
     BRSt<1>& st = g.st;
@@ -555,8 +664,9 @@ BB_DEV bool bs_unit_a(const DevModel& M, const DevState& S, const RunArgs& A, co
     if (!(meta & BRM_VALID)) return false;
     const bool a0 = meta & BRM_A0, a1 = meta & BRM_A1;
     const long long i0 = st.i0[0];
-    bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[meta >> 12].pad, a0, a1, g);
-    g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step) : bs_draw(A.seed, i0, step);
+    if (MS && !ms.last) bs_load_mu_om(S, i0, a0, a1, g);
+    else bs_load_state(M, S, hs_m, hs_o, i0, i0 - sg[meta >> 12].pad, a0, a1, g);
+    g.e = BS_G_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step, (unsigned)ms.smp) : bs_draw(A.seed, i0, step, (unsigned)ms.smp);
     g.z = bs_z(g.mu, g.om, g.e, &g.sp, &g.sg);          // the owner's own sample of this step, again
     g.a = bb_d2{g.e.x * g.sg.x, g.e.y * g.sg.y};
     g.h = bb_d2{g.sg.x * bb_rcp(g.sp.x), g.sg.y * bb_rcp(g.sp.y)};
@@ -564,11 +674,11 @@ BB_DEV bool bs_unit_a(const DevModel& M, const DevState& S, const RunArgs& A, co
     return true;
 }
 // part B: gradient from the units' sums and the staged forms of THIS step, optimiser, everything out; the next step's sample, staged
-template <int KIND, int TT>
+template <int KIND, int TT, bool MS = false>
 BB_DEV bool bs_unit_b(const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, const BRSeg* sg, double* hs_m, double* hs_o,
-                      const BBSlot wslot, unsigned step, double* lds, BSG& g, int NBs) {
+                      const BBSlot wslot, unsigned step, double* lds, BSG& g, int NBs, const BSMs& ms) {
     const BBLds& L = Y.L;
-    const int buf = (int)(step & 1u), nbuf = buf ^ 1;
+    const int buf = ms.buf, nbuf = buf ^ 1;
     const int E = (KIND == 1 || KIND == 4) ? M.E : 1;
     const int* envt = (const int*)(lds + Y.envt);
     const double* aq = lds + Y.hbuf;
@@ -639,13 +749,17 @@ BB_DEV bool bs_unit_b(const DevModel& M, const DevState& S, const RunArgs& A, co
     }
     gl0 -= (zv0 - pm0) * iv0;
     gl1 -= (zv1 - pm1) * iv1;
-    const bool bad = bs_apply_store(M, S, A, wslot, hs_m, hs_o, i0, ih, a0, a1, gl0, gl1, g);
-    const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, step + 1u) : bs_draw(A.seed, i0, step + 1u);
-    bs_put_u<KIND>(lds, M, Y, A, st, nbuf, bs_z(g.mu, g.om, en, &g.sp, &g.sg));
+    const bool bad = bs_finish_pair<MS>(M, S, A, wslot, hs_m, hs_o, i0, ih, a0, a1, gl0, gl1, g, ms);
+    const bb_d2 en = BS_S_INLINE_DRAW ? bs_draw_inline(A.seed, i0, ms.nstep, ms.nstream) : bs_draw(A.seed, i0, ms.nstep, ms.nstream);
+    const bb_d2 zn = bs_z(g.mu, g.om, en, &g.sp, &g.sg);
+    bs_put_u<KIND>(lds, M, Y, A, st, nbuf, zn);
+    if (MS && ms.el_next) g.el += bs_el_pair<KIND, TT>(lds, M, Y, A, st, zn, g.sp);
     return bad;
 }
-template <int KIND, int TT>
-BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv) {
+template <int KIND, int TT, bool MS = false>
+BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, int NB, int P, unsigned step, const BBSlot wslot, int* bad_any, BSG* gv,
+                        const BSMs ms_ = BSMs{1, 0, -1, true, false, 0u, 0u}) {
+    const BSMs ms = (MS && ms_.buf >= 0) ? ms_ : bs_ms_plain(step);
     double* lds = cx.lds;
     const BBLds& L = Y.L;
     const BBTile t = KIND == 2 ? br_tile_geno(M, S, cx.block, NB) : br_tile(M, A, cx.block, NB);
@@ -664,24 +778,31 @@ BB_DEV void bs_update_u(BBCtx& cx, const DevModel& M, const DevState& S, const R
     BB_PASS(cx, tid) {
         BSG& g = BB_PSTATE(gv, tid);
         g.ok = 0;
-        if (k0 < P) bs_unit_a<KIND, TT>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k0 * cx.nthr, lspan, step, lds, g);
+        if (k0 < P) bs_unit_a<KIND, TT, MS>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k0 * cx.nthr, lspan, step, lds, g, ms);
     }
     BB_SYNC(cx);                     // the units' sums (As, Qs; genotype model: w As) are in LDS
     BB_PASS(cx, tid) {
         BSG& g = BB_PSTATE(gv, tid);
         bool bad = false;
-        if (g.ok) bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g, NB);
+        if (g.ok) bad = bs_unit_b<KIND, TT, MS>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g, NB, ms);
         for (int k = k0 + 1; k < P; ++k)
-            if (bs_unit_a<KIND, TT>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k * cx.nthr, lspan, step, lds, g))
-                bad = bs_unit_b<KIND, TT>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g, NB) || bad;
+            if (bs_unit_a<KIND, TT, MS>(M, S, A, Y, t, sg, nseg, g0t, g1t, hs_m, hs_o, tid + k * cx.nthr, lspan, step, lds, g, ms))
+                bad = bs_unit_b<KIND, TT, MS>(M, S, A, Y, sg, hs_m, hs_o, wslot, step, lds, g, NB, ms) || bad;
         if (bad) *bad_any = 1;
     }
     BB_SYNC(cx);                     // the next step's tables are complete
     BB_STAMP(cx, S, 28);
 }
 
+// One step of the MS form, as the emulation and the kernel both walk it: the bookkeeping of (step, sample) -> what the passes need
+BB_DEV BSMs bs_ms_of(const RunArgs& A, unsigned long long step, int smp, int NS, bool el_this_step, bool el_next_step) {
+    const bool last = smp == NS - 1;
+    const unsigned long long xc = step * (unsigned long long)NS + (unsigned long long)smp;
+    return BSMs{NS, smp, (int)(xc & 1ull), last, last ? el_next_step : el_this_step, (unsigned)(last ? step + 1ull : step), last ? 0u : (unsigned)(smp + 1)};
+}
+
 #ifndef BB_EMU
-template <int KIND, int NT, int TT>
+template <int KIND, int NT, int TT, bool MS = false>
 __global__ void __launch_bounds__(NT) k_stream(const DevModel* __restrict__ Mp, const DevState* __restrict__ Sp, const BRLay* __restrict__ Yp,
                                                RunArgs A, int NB, int nsteps, int P) {
     const DevModel& M = *Mp;
@@ -702,19 +823,35 @@ __global__ void __launch_bounds__(NT) k_stream(const DevModel* __restrict__ Mp, 
     BRSt<1>* nost = nullptr;
     int done = 0;
     if (!dead) {
-        bs_sample0<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step0, &g);
+        const int NS = MS ? A.S : 1;
+        // ELBO recording (MS): position inside the recording period and the ring slot, carried like the window slot (as k_res)
+        int ec = (MS && A.elbo_every > 0) ? bb_uniform((int)(step0 % (unsigned long long)A.elbo_every)) : 1;
+        int ring = (MS && A.elbo_every > 0) ? bb_uniform((int)(((step0 + (unsigned long long)A.elbo_every - 1ull) / (unsigned long long)A.elbo_every) % BB_ELBO_RING)) : 0;
+        bs_sample0<KIND, TT, MS>(cx, M, S, A, Y, NB, P, (unsigned)step0, &g, (int)((step0 * (unsigned long long)NS) & 1ull), MS && A.elbo_every > 0 && ec == 0);
         BBSlotCtr sc = bb_slot_init(A, step0);
         for (; done < nsteps; ++done, bb_slot_next(A, sc)) {
             const unsigned long long step = step0 + (unsigned long long)done;
             const BBSlot wslot = bb_slot_now(A, sc);
-            bs_moments<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, &g);
-            bs_touch0<KIND, TT>(cx, M, S, A, Y, wslot);
-            br_row_publish<1, true, false>(cx, M, S, Y, nost, A.xepoch0 + (unsigned)(step + 1));
-            br_xchg_lead<false>(cx, M, S, A, Y, step, ok_slot);
-            br_xchg_consume<KIND, 1, false, false>(cx, M, S, A, Y, nost, step, ok_slot);
-            if (*ok_slot == 0) break;
-            bs_update_l<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any, &g);
-            bs_update_u<KIND, TT>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any, &g);
+            const bool want_el = MS && A.elbo_every > 0 && ec == 0;
+            const int ec1 = (MS && A.elbo_every > 0) ? (ec + 1 == A.elbo_every ? 0 : ec + 1) : 1;
+            bool stop = false;
+            for (int smp = 0; smp < NS; ++smp) {
+                const BSMs ms = MS ? bs_ms_of(A, step, smp, NS, want_el, MS && A.elbo_every > 0 && ec1 == 0) : bs_ms_plain((unsigned)step);
+                const unsigned long long xc = MS ? step * (unsigned long long)NS + (unsigned long long)smp : step;
+                bs_moments<KIND, TT, MS>(cx, M, S, A, Y, NB, P, (unsigned)step, &g, ms.buf, want_el);
+                bs_touch0<KIND, TT>(cx, M, S, A, Y, wslot);
+                br_row_publish<1, true, MS>(cx, M, S, Y, nost, A.xepoch0 + (unsigned)(xc + 1), want_el);
+                br_xchg_lead<false>(cx, M, S, A, Y, xc, ok_slot);
+                br_xchg_consume<KIND, 1, false, MS>(cx, M, S, A, Y, nost, xc, ok_slot, want_el, ring, smp);
+                if (*ok_slot == 0) { stop = true; break; }
+                bs_update_l<KIND, TT, MS>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any, &g, ms);
+                bs_update_u<KIND, TT, MS>(cx, M, S, A, Y, NB, P, (unsigned)step, wslot, bad_any, &g, ms);
+            }
+            if (stop) break;
+            if (MS && A.elbo_every > 0) {
+                if (ec == 0) ring = ring + 1 == BB_ELBO_RING ? 0 : ring + 1;
+                ec = ec1;
+            }
         }
     }
     if (threadIdx.x == 0) {

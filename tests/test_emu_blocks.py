@@ -469,3 +469,35 @@ def test_sharded_resident_launch_several_samples_and_elbo_trace(emu_lib, monkeyp
     c.case_p2p_resident(emu_lib, name, 2, samples_per_step=2, elbo_every=1)
     c.case_p2p_resident(emu_lib, name, 3, steps=8, samples_per_step=3, elbo_every=2)
     c.case_multi_device_handle(emu_lib, name, n=2, samples_per_step=2, elbo_every=1)
+
+
+@pytest.mark.parametrize("name,nb,nthr", [("fitness_neutral_heavy", 140, 128), ("multienv_T8", 40, 64), ("genotype_T8", 100, 128), ("genotype_runs", 110, 128),
+                                          ("replicate_R3_T6", 50, 128), ("multienv_replicate_T6", 20, 128)])
+def test_streaming_resident_launch_several_samples_and_elbo_trace(emu_lib, monkeypatch, name, nb, nthr):
+    """k_stream's MS form (round 4): several MC samples per step -- each an exchange of its own, the gradient sums in memory, the last sample
+    updates -- and the ELBO trace, against the literal oracle's loop (S = 2 exact window; S = 3 with the trace, running window)."""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_STREAM", "1")
+    sp = c.synth(name, seed=2)
+    e, a, b, _ = c._trajectory(emu_lib, sp, 9, 2, "TruncatedADAGrad", window=5, resum_every=1, launch_mode=2)
+    k = e.stats()["resident_kernel"]
+    e.close()
+    assert k == 3 and a < 1e-10 and b < 1e-10, (k, a, b)
+    e, a, b, tr = c._trajectory(emu_lib, sp, 11, 3, "DecayedADAGrad", elbo_every=1, launch_mode=2)
+    got = e.elbo_trace(0, 11)
+    k = e.stats()["resident_kernel"]
+    e.close()
+    assert k == 3 and a < 1e-10 and b < 1e-10, (k, a, b)
+    assert np.abs(got - tr).max() <= 1e-10 * np.abs(tr).max()
+    # two calls of run (the launch's first sample is formed again from the stored parameters), recording every second step
+    with c.make_engine(sp, emu_lib, seed=11, samples_per_step=2, elbo_every=2, launch_mode=2, window=5) as e2:
+        e2.run(5); e2.run(4)
+        p2 = e2.get_params()
+        t2 = e2.elbo_trace(0, 5)
+    with c.make_engine(sp, emu_lib, seed=11, samples_per_step=2, elbo_every=2, launch_mode=1, window=5) as e1:
+        e1.run(9)
+        p1 = e1.get_params()
+        t1 = e1.elbo_trace(0, 5)
+    assert np.abs(p2[0] - p1[0]).max() < 1e-9 and np.abs(p2[1] - p1[1]).max() < 1e-9
+    assert np.abs(t2 - t1).max() <= 1e-10 * np.abs(t1).max()

@@ -354,6 +354,42 @@ def test_streaming_resident_launch_full_size_c5(hip_lib):
     assert np.all(np.isfinite(outs[1][0])) and np.abs(outs[0][0] - outs[1][0]).max() < 1e-8 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-8
 
 
+@pytest.mark.parametrize("name,nb,nthr", [("fitness_neutral_heavy", 140, 1024), ("multienv_T8", 150, 1024), ("genotype_T8", 250, 512), ("genotype_T8", 500, 1024),
+                                          ("replicate_R3_T6", 100, 512), ("multienv_replicate_T6", 75, 1024)])
+def test_streaming_resident_launch_several_samples_and_elbo_trace(hip_lib, monkeypatch, name, nb, nthr):
+    """k_stream<.., true> (round 4): several MC samples per step and the ELBO trace with the state streamed -- against the literal oracle's loop."""
+    monkeypatch.setenv("BB_TUNE_NB", str(nb))
+    monkeypatch.setenv("BB_TUNE_NTHR", str(nthr))
+    monkeypatch.setenv("BB_TUNE_STREAM", "1")
+    sp = c.synth(name, seed=2)
+    e, a, b, _ = c._trajectory(hip_lib, sp, 9, 2, "TruncatedADAGrad", window=5, resum_every=1, launch_mode=2)
+    nm = e.kernel_name()
+    e.close()
+    assert nm.startswith("k_stream<") and nm.endswith(",true>") and a < 1e-10 and b < 1e-10, (nm, a, b)
+    e, a, b, tr = c._trajectory(hip_lib, sp, 11, 3, "DecayedADAGrad", elbo_every=1, launch_mode=2)
+    got = e.elbo_trace(0, 11)
+    e.close()
+    assert a < 1e-10 and b < 1e-10, (a, b)
+    assert np.abs(got - tr).max() <= 1e-10 * np.abs(tr).max()
+
+
+def test_streaming_resident_launch_full_size_replicates(hip_lib):
+    """`replicate_fitness_normal` 80 000 x 6 x 3 (2.2 M latents: beyond the register file) on ONE GPU: k_stream<3,1024,6> -- three loglambda
+    segments per tile, T = 6 on four lanes per barcode -- against the two-kernel step, 41 steps."""
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import port
+    sp = port.spec_from_workload(synth.replicate_fitness_normal(80_000, 6, 3, 43))
+    outs = []
+    for mode in (1, 2):
+        with make_engine(sp, hip_lib, seed=7, launch_mode=mode) as e:
+            e.run(41)
+            outs.append(e.get_params())
+            if mode == 2:
+                assert e.kernel_name() == "k_stream<3,1024,6>", e.kernel_name()
+    assert np.all(np.isfinite(outs[1][0])) and np.abs(outs[0][0] - outs[1][0]).max() < 1e-8 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-8
+
+
 @pytest.mark.parametrize("name", ["genotype_runs", "genotype_T8", "genotype_odd"])
 def test_genotype_regrouped_inside_the_library(hip_lib, name):
     """geno_idx in order of appearance (a genotype's mutants scattered, as utils.data_to_arrays delivers them): regrouped by the
