@@ -39,7 +39,7 @@ for n in (2, 4):          # (round 4: the N > 1 bench line, short form against l
     cp(f"{tag}_rehearsal{n}_20.json", f"bench_{n}ranks_one_gpu_rehearsal_20_steps_warmup_5.json")
     cp(f"{tag}_rehearsal{n}_4000.json", f"bench_{n}ranks_one_gpu_rehearsal_4000_steps.json")
 for src, dst in ((f"{tag}_stream_replicates.txt", "k_stream_replicate_80000x6x3.txt"), (f"{tag}_stamps_C5.txt", "stamps_C5_k_stream.txt"),
-                 (f"{tag}_stamps_C5rank.txt", "stamps_C5rank.txt"), (f"{tag}_stamps_C3.txt", "stamps_C3.txt")):
+                 (f"{tag}_stamps_C5rank.txt", "stamps_C5rank.txt"), (f"{tag}_stamps_C3.txt", "stamps_C3.txt"), (f"{tag}_ms_rates_C5.txt", "ms_rates_C5.txt")):
     cp(src, dst)
 # (the traffic record names the COMMITTED directory its counter rows sit in, not the scratch tag; it is restamped only when this round's
 #  counter passes exist -- a partial round must neither crash the collection nor point bench.py's replayed `traffic` at a directory

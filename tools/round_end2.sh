@@ -32,3 +32,4 @@ timeout -k 10 300 python tools/stream_replicates.py 2>&1 | grep -v amdgpu > $O/$
 WL=genotype_fitness_normal timeout -k 10 300 python tools/xp.py run base 2>&1 | grep -v amdgpu > $O/${TAG}_stamps_C5.txt
 WL=genotype_fitness_normal B=25000 G=626 timeout -k 10 200 python tools/xp.py run base 2>&1 | grep -v amdgpu > $O/${TAG}_stamps_C5rank.txt
 WL=replicate_fitness_normal timeout -k 10 200 python tools/xp.py run base 2>&1 | grep -v amdgpu > $O/${TAG}_stamps_C3.txt
+WL=C5 timeout -k 10 400 python tools/ms_rates.py 2>&1 | grep -v amdgpu > $O/${TAG}_ms_rates_C5.txt
