@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -2173,10 +2174,25 @@ static int run_finish(bb_handle* h) {
 extern "C" int bb_run(bb_handle* h, int64_t n_steps) {
     if (!h || n_steps < 0) return bb_fail(BB_ERR_INVALID, "bad argument");
     if (!h->shards.empty()) return group_run(h, n_steps);
+#ifdef BB_HOST_TIMES          // diagnostics (tools/launch_probe.py): where the host's share of a run goes
+    timespec ht0, ht1, ht2, ht3;
+    clock_gettime(CLOCK_MONOTONIC, &ht0);
+#endif
     BB_ENTER(h);
+#ifdef BB_HOST_TIMES
+    clock_gettime(CLOCK_MONOTONIC, &ht1);
+#endif
     int rc = run_enqueue(h, n_steps);
     if (rc) return rc;
+#ifdef BB_HOST_TIMES
+    clock_gettime(CLOCK_MONOTONIC, &ht2);
+#endif
     rc = run_finish(h);
+#ifdef BB_HOST_TIMES
+    clock_gettime(CLOCK_MONOTONIC, &ht3);
+    auto us = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+    fprintf(stderr, "[bb_run %lld] device guard %.1f us, enqueue %.1f us, wait + status %.1f us, events %.1f us\n", (long long)n_steps, us(ht0, ht1), us(ht1, ht2), us(ht2, ht3), h->last_run_ms * 1e3);
+#endif
 #ifndef BB_EMU
     if (h->theta_stale && h->comm) {
         // Collective, so EVERY rank takes it whatever its own launch reported: the timeout word and the non-finite flag run_finish
