@@ -10,8 +10,9 @@ from barbay_jl_amd import synth
 
 for B in [int(x) for x in sys.argv[1:]] or [16000, 17000, 18000, 20000]:
     wl = synth.replicate_fitness_normal(B, 6, 3, 43)
-    for nthr in (1024, 512):
+    for nthr, stream in ((1024, 0), (512, 0), (1024, 1)):
         os.environ["BB_TUNE_NTHR"] = str(nthr)
+        os.environ["BB_TUNE_STREAM"] = str(stream)          # (1: the streaming-resident launch on a shape the register file holds)
         e = bb.Engine(wl.kind, wl.counts, wl.n_neutral, wl.n_bc, seed=42)
         e.run(1000)
         e.run(4000)
