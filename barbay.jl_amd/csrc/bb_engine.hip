@@ -262,6 +262,7 @@ struct bb_handle {
 #ifndef BB_EMU
     hipGraphExec_t graph = nullptr;
     int graph_steps = 0;
+    unsigned launch_seq = 0;           // resident launches of this handle so far (RunArgs.launch_tag)
     bool graph_failed = false;         // capture / instantiation failed once (e.g. a collective that cannot be captured): stay eager
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bb_ncclComm_t comm = nullptr;
@@ -1063,6 +1064,8 @@ static int launch_persistent(bb_handle* h, long long nsteps) {
     if (h->p2p_first && nsteps > 0) { A.spin_limit = 1u << 25; h->p2p_first = false; }   // launch skew between the ranks' processes
     do {                                                  // (nsteps == 0: one launch that only loads and stores the state)
         const int n = (int)std::min<long long>(nsteps, 4096);
+        if (++h->launch_seq == 0u) h->launch_seq = 1u;
+        A.launch_tag = h->launch_seq;
         if (h->res_stream) hipLaunchKernelGGL(stream_kernel(h->M.kind, h->nthr, uniform_T(h->M), nullptr, res_ms(h)), dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream,
                                               (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n, h->res_P);
         else if (kr) hipLaunchKernelGGL(kr, dim3(h->res_nblk), dim3(h->nthr), h->lds_doubles_p * 8, h->stream, (const DevModel*)h->dM, (const DevState*)h->dS, (const BRLay*)h->dY, A, h->res_NB, n);
@@ -1401,6 +1404,7 @@ static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
     BB_TRY(dalloc(h, &S.grow, (size_t)(h->nblk + 8 + 16 * BB_NG_MAX) * (M.K + 2 * M.nt1)));      // (+ 16 groups x 16: a leader's eight loads in flight run past its last member, bb_gran_poll8)
     BB_TRY(dalloc(h, &S.gxrow, (size_t)2 * BB_NG_MAX * (M.K + 2 * M.nt1)));
     BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 2 * BB_NG_MAX)));
+    BB_TRY(dalloc(h, &S.xtab, (size_t)BB_NG_MAX));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));

@@ -347,6 +347,29 @@ BB_DEV void bb_set_word(unsigned* word, unsigned v) {
 #endif
 }
 
+BB_DEV void bb_set_word64(unsigned long long* word, unsigned long long v) {
+#ifdef BB_EMU
+    *word = v;
+#else
+    __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+BB_DEV unsigned long long bb_get_word64(const unsigned long long* word) {
+#ifdef BB_EMU
+    return *word;
+#else
+    return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// the XCD (accelerator complex die) this wave runs on: its workgroups share an L2
+BB_DEV int br_xcc_id() {
+#ifdef BB_EMU
+    return 0;
+#else
+    return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u);          // hwreg(HW_REG_XCC_ID, 0, 4)
+#endif
+}
+
 // ---- self-validating rows (k_res on one GPU, BR_TG) -------------------------------------------------------------------
 // A row entry travels as ONE 16-byte write-through store {lo32, tag, hi32, tag}: two 8-byte granules that each carry the step's
 // tag (= the ready words' epoch: base + step + 1, only ever growing).  A reader takes a value only when both tags match, so the
@@ -376,6 +399,15 @@ BB_DEV void bb_gran_st(bb_gran* p, double v, unsigned tag) {
     bb_v4u g = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
     if (SYS) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(g) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(g) : "memory");
+#endif
+}
+// the same entry by a PLAIN store: the line stays (dirty) in the storing XCD's L2 -- only a reader on the SAME XCD ever sees it
+BB_DEV void bb_gran_st_l2(bb_gran* p, double v, unsigned tag) {
+#ifdef BB_EMU
+    bb_gran_st(p, v, tag);
+#else
+    bb_v4u g = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(g) : "memory");
 #endif
 }
 // The entries base[off + i * stride], i < 8: poll until those with i < n carry `tag` in both halves, then their values in order

@@ -52,6 +52,10 @@
 #ifndef BR_UNIT_PRIO
 #define BR_UNIT_PRIO 1
 #endif
+// BR_ROW_L2: a tile on its group leader's XCD stores its row with plain stores (br_row_publish); 0 = always write-through
+#ifndef BR_ROW_L2
+#define BR_ROW_L2 1
+#endif
 #ifndef BR_UNIT_PRIO_LEVEL
 #define BR_UNIT_PRIO_LEVEL 3
 #endif
@@ -559,6 +563,13 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
             if (tid == 0) li[0] = ((const int*)(src + nd))[0];
         } else if (tid == 0) li[0] = br_build_segs<KIND>(sg, M, Y, t, cx.block == 0, g0, g1);
         if (tid == 0) { li[1] = bb_get_word(S.gbar + 1) == 0u ? 1 : 0; li[2] = ncol_or_neg < 0 ? t.nbt : ncol_or_neg; }
+        if (tid == 0) {
+            // Same-XCD first hop (BR_ROW_L2): li[4] = 0 not known yet / 1 this tile runs on its group leader's XCD / -1 it does not;
+            // li[5] = own XCC id, li[6] = this launch's tag, li[7] = groups.  The leaders say where they run.
+            const int xcc = br_xcc_id(), NG = bbp_groups(A);
+            li[4] = 0; li[5] = xcc; li[6] = (int)A.launch_tag; li[7] = NG;
+            if (BR_ROW_L2 && cx.block < NG) bb_set_word64(S.xtab + cx.block, ((unsigned long long)A.launch_tag << 32) | (unsigned)xcc);
+        }
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
         for (int i = tid; i < Y.zlw * Y.NBT; i += cx.nthr) lds[Y.zl + i] = 0.0;
         for (int i = tid; i < Y.nst * Y.stw; i += cx.nthr) lds[Y.st[0] + i] = 0.0;
@@ -901,7 +912,22 @@ BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, cons
         if (BR_PUB_COALESCED) {
             // the row leaves as whole lines from the first waves (one store instruction per 64 entries) instead of one 16-byte
             // partial line write per entry from a dozen waves
-            BB_PASS(cx, tid) { for (int j = tid; j < KK; j += cx.nthr) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch); }
+            // Same-XCD first hop: a tile's row is read by ONE tile, its group's leader -- and the dispatcher deals workgroups to the XCDs in
+            // turn, so leader g and its members g + NG j (NG = 8, 16, 32) share an XCD and with it an L2.  A PLAIN store leaves the entry in
+            // that L2, where the leader's sc1 polls find it after an L2 round trip instead of a trip through the fabric: C2 11.35 -> 10.89 us per
+            // step (profiles/r04i_same_xcd_first_hop).  Nothing rests on the dispatch order: a member stores write-through (sc1) until it has
+            // read, from its leader's entry of this launch, that both run on the same XCC, and for good if they do not.
+            int* li = (int*)(lds + Y.L.misc);
+            BB_PASS(cx, tid) {
+                if (BR_ROW_L2 && li[4] > 0) { for (int j = tid; j < KK; j += cx.nthr) bb_gran_st_l2(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch); }
+                else for (int j = tid; j < KK; j += cx.nthr) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch);
+                if (BR_ROW_L2 && tid == 0 && li[4] == 0) {
+                    int g = cx.block;
+                    while (g >= li[7]) g -= li[7];          // (at most 31 rounds, the first steps of a launch only)
+                    const unsigned long long v = bb_get_word64(S.xtab + g);
+                    if ((unsigned)(v >> 32) == (unsigned)li[6]) li[4] = (int)(unsigned)v == li[5] ? 1 : -1;
+                }
+            }
         }
         BB_STAMP(cx, S, 24);
         BB_STAMP_RT(cx, S, 29);

@@ -90,6 +90,8 @@ struct DevState {
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
     struct bb_gran *grow, *gxrow;     // k_res on one GPU: the same rows as self-validating 16-byte entries (bb_persist.h, BR_TG): [nblk][K + 2 nt1], [2][16][K + 2 nt1]
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
+    unsigned long long *xtab;         // [BB_NG_MAX] k_res / k_stream: where the group leaders run -- {launch tag << 32 | XCC id}, written by every leader at the start of
+                                      //   a launch; a member whose own XCC id is the leader's stores its row with plain stores (br_row_publish)
     const double *segtab;             // k_res / k_stream: the tiles' segment tables, built on the host (bb_engine.hip, host_tables): [tiles][segtab_stride] doubles,
     int segtab_stride;                //   each = (4 + 4 R + 1) BRSeg records + one word with their count; nullptr: thread 0 of a tile builds its own
     const int *ldstab;                // ... and the tile-independent LDS descriptor tables [rowmap 2 K | tmap K | ftab 4 Ttot | rtab 4 R]
@@ -112,6 +114,7 @@ struct RunArgs {
     int rank, world;                  // of the sharded run (0, 1 otherwise)
     unsigned xepoch0;                 // base of the ready / inbox words of the resident launch: they carry base + step + 1 and only ever grow (bb_persist.h)
     unsigned spin_limit;              // polls of one ready word before a resident launch gives up (the first launch of a sharded run gets more)
+    unsigned launch_tag;              // counts the handle's resident launches (never 0): what a launch's entries in DevState.xtab carry
     int nblk;                         // blocks of the barcode grid
     int nblk_alloc;                   // tiles the exchange / stamp buffers were sized for (+ 8)
     int ng;                           // groups of the exchange's first hop (8; k_res on one GPU: 16 where the tile has the threads for it)
