@@ -1534,9 +1534,6 @@ template <int KIND, int P, bool XG, bool MS = false>
 BB_DEV void br_xchg_consume(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BRLay& Y, BRSt<P>* stv,
                             unsigned long long xc, int* ok_slot, bool want_el = false, int ring = 0, int smp = 0, int slot = -1) {
     const unsigned epoch = A.xepoch0 + (unsigned)(xc + 1);
-#ifdef BR_XP_DELAY          /* experiment: only the leaders poll the group rows at first -- what the second hop costs without 248 other pollers */
-    if (cx.block >= bbp_groups(A)) __builtin_amdgcn_s_sleep(BR_XP_DELAY);
-#endif
     if (XG && BR_TG) bbp_consume_tgx(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
     else if (BR_TG) bbp_consume_tg(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot);
     else bbp_consume<XG, !XG>(cx, M, S, A, Y.L, (int)(xc & 1), epoch, ok_slot, epoch);
