@@ -72,6 +72,7 @@ class bb_stats(C.Structure):
         ("persistent_pairs", C.c_int32), ("launches_last_run", C.c_int32), ("resident_kernel", C.c_int32),
         ("geno_lo", C.c_int32), ("geno_hi", C.c_int32),
         ("device_bytes", C.c_int64), ("window_row", C.c_int64),
+        ("rows_same_xcd", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

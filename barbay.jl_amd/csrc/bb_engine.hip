@@ -1401,10 +1401,11 @@ static int create_inner(const bb_model_desc* md, const bb_advi_opts* opts, bb_ha
 #endif
     BB_TRY(dalloc(h, &S.prow, (size_t)(h->nblk + 8) * (M.K + 2 * M.nt1)));      // (+ 8: k_res's own tile map may need a few tiles more)
     BB_TRY(dalloc(h, &S.xrow, (size_t)2 * BB_NG_MAX * (M.K + 2 * M.nt1)));
-    BB_TRY(dalloc(h, &S.grow, (size_t)(h->nblk + 8 + 16 * BB_NG_MAX) * (M.K + 2 * M.nt1)));      // (+ 16 groups x 16: a leader's eight loads in flight run past its last member, bb_gran_poll8)
+    BB_TRY(dalloc(h, &S.grow, (size_t)(h->nblk + 8 + 16 * BB_NG_MAX) * bb_row_stride(M.K + 2 * M.nt1)));      // (+ 16 groups x 16: a leader's eight loads in flight run past its last member, bb_gran_poll8)
     BB_TRY(dalloc(h, &S.gxrow, (size_t)2 * BB_NG_MAX * (M.K + 2 * M.nt1)));
     BB_TRY(dalloc(h, &S.rdy, (size_t)32 * (h->nblk + 8 + 2 * BB_NG_MAX)));
     BB_TRY(dalloc(h, &S.xtab, (size_t)BB_NG_MAX));
+    BB_TRY(dalloc(h, &S.xsel, (size_t)h->nblk + 8));
     BB_TRY(dalloc(h, &S.ztheta, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.gsum, (size_t)std::max(M.G, 1)));
     BB_TRY(dalloc(h, &S.ds, (size_t)M.nb));
@@ -1605,6 +1606,7 @@ static RunArgs make_args(const bb_handle* h, long long step, int sample, int S, 
     A.world = h->o.world_size;
     A.xepoch0 = h->epoch0;
     A.spin_limit = 1u << 23;                  // ~1 us per poll: seconds, not milliseconds
+    { const char* ev = getenv("BB_TUNE_ROW_L2"); A.row_l2 = (ev && atoi(ev) == 0) ? 0 : 1; }
     A.nblk = h->nblk;
     A.nblk_alloc = h->nblk;
     A.ng = 8;
@@ -2686,6 +2688,7 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
             if ((rc = bb_get_stats(h->shards[i], &t))) break;
             s->bytes_per_step += t.bytes_per_step; s->bytes_sample += t.bytes_sample; s->bytes_update += t.bytes_update;
             s->n_blocks += t.n_blocks;
+            s->rows_same_xcd += t.rows_same_xcd;
             s->device_bytes += t.device_bytes;
             s->last_run_ms = std::max(s->last_run_ms, t.last_run_ms);
             s->persistent_pairs = std::min(s->persistent_pairs, t.persistent_pairs);
@@ -2719,6 +2722,12 @@ extern "C" int bb_get_stats(bb_handle* h, bb_stats* s) {
     s->persistent_pairs = h->persist_P;
     s->launches_last_run = h->launches_last_run;
     s->resident_kernel = h->res_P > 0 ? (h->res_stream ? 3 : 2) : (h->persist_P > 0 ? 1 : 0);
+    if (h->res_P > 0 && h->res_nblk > 0) {          // (k_res / k_stream: what the tiles of the last launch decided about their row stores)
+        std::vector<int> sel((size_t)h->res_nblk);
+        int rc = d2h(sel.data(), h->S.xsel, sel.size() * sizeof(int), h->stream);
+        if (rc) return rc;
+        for (int v : sel) s->rows_same_xcd += v > 0 ? 1 : 0;
+    }
     return BB_OK;
 }
 

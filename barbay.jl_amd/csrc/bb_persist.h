@@ -347,6 +347,10 @@ BB_DEV void bb_set_word(unsigned* word, unsigned v) {
 #endif
 }
 
+// entries between the rows of two tiles in DevState.grow.  (Measured and dropped, round 4: every row on a 128-byte line of its own, stride
+// rounded up to 8 entries -- C2's leaders then walk their 32 members' rows 8 KB apart, a power of two, and the step went 10.80 -> 10.93 us;
+// rows of neighbouring tiles, which run on different XCDs, therefore share a line at their ends: each L2 writes back the bytes it dirtied.)
+BB_HD int bb_row_stride(int KK) { return KK; }
 BB_DEV void bb_set_word64(unsigned long long* word, unsigned long long v) {
 #ifdef BB_EMU
     *word = v;
@@ -484,7 +488,7 @@ BB_DEV long long bbx_slot(const RunArgs& A, int par, int src, int g);
 #endif
 template <bool XG = false>
 BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S, const RunArgs& A, const BBLds& L, int par, unsigned epoch, int* ok) {
-    const int KK = M.K + 2 * M.nt1, NG = bbp_groups(A), g = cx.block;
+    const int KK = M.K + 2 * M.nt1, KS = bb_row_stride(KK), NG = bbp_groups(A), g = cx.block;
     const int members = (A.nblk - g + NG - 1) / NG;
     constexpr bool PAR = XG || BR_LEAD_PAR;
     const int KKP = (KK + 63) & ~63, chunks = (members + 7) >> 3;
@@ -502,7 +506,7 @@ BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S
                 for (int c = q; c < chunks; c += NQ) {
                     double v[8];
                     const int m0 = 8 * c, n = members - m0 < 8 ? members - m0 : 8;
-                    if (!bb_gran_poll8(S.grow + (long long)g * KK, (unsigned)(m0 * NG * KK + k), (unsigned)(NG * KK), n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
+                    if (!bb_gran_poll8(S.grow + (long long)g * KS, (unsigned)(m0 * NG * KS + k), (unsigned)(NG * KS), n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
                     double s = 0.0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) s += v[i];
@@ -532,7 +536,7 @@ BB_DEV void bbp_leader_reduce_tg(BBCtx& cx, const DevModel& M, const DevState& S
             for (int m0 = 0; m0 < members; m0 += 8) {
                 double v[8];
                 const int n = members - m0 < 8 ? members - m0 : 8;
-                if (!bb_gran_poll8(S.grow + (long long)g * KK, (unsigned)(m0 * NG * KK + k), (unsigned)(NG * KK), n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
+                if (!bb_gran_poll8(S.grow + (long long)g * KS, (unsigned)(m0 * NG * KS + k), (unsigned)(NG * KS), n, epoch, act, S.gbar + 1, A.spin_limit, v)) *ok = 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s += v[i];
             }

@@ -567,7 +567,8 @@ BB_DEV void br_tile_setup(BBCtx& cx, const DevModel& M, const DevState& S, const
             // Same-XCD first hop (BR_ROW_L2): li[4] = 0 not known yet / 1 this tile runs on its group leader's XCD / -1 it does not;
             // li[5] = own XCC id, li[6] = this launch's tag, li[7] = groups.  The leaders say where they run.
             const int xcc = br_xcc_id(), NG = bbp_groups(A);
-            li[4] = 0; li[5] = xcc; li[6] = (int)A.launch_tag; li[7] = NG;
+            li[4] = (BR_ROW_L2 && A.row_l2) ? 0 : -1; li[5] = xcc; li[6] = (int)A.launch_tag; li[7] = NG;
+            S.xsel[cx.block] = li[4];
             if (BR_ROW_L2 && cx.block < NG) bb_set_word64(S.xtab + cx.block, ((unsigned long long)A.launch_tag << 32) | (unsigned)xcc);
         }
         for (int k = tid; k < KK; k += cx.nthr) lds[L.wk + k] = 0.0;
@@ -859,7 +860,7 @@ template <int P, bool TG = false, bool MS = false>
 BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, const BRLay& Y, BRSt<P>* stv, unsigned epoch, bool want_el = false) {
     double* lds = cx.lds;
     BB_STAMP(cx, S, 23);
-    const int KK = M.K + 2 * M.nt1;
+    const int KK = M.K + 2 * M.nt1, KS = bb_row_stride(KK);
     const int* rm = (const int*)(lds + Y.rowmap);
     const int nbt = ((const int*)(lds + Y.L.misc))[2];          // barcodes of this tile: column entries per time-pair class
     BB_PASS(cx, tid) {
@@ -875,7 +876,7 @@ BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, cons
 #endif
             }
             if (TG && BR_PUB_COALESCED) lds[Y.L.wk + M.K - 2] = e;
-            else if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + M.K - 2, e, epoch);
+            else if (TG) bb_gran_st(S.grow + (long long)cx.block * KS + M.K - 2, e, epoch);
             else bb_st<true>(S.prow + (long long)cx.block * KK + M.K - 2, e);
         }
         for (int j = tid >> 4; j < M.K; j += cx.nthr >> 4) {
@@ -894,12 +895,12 @@ BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, cons
 #endif
             if (c == 0) {
                 if (TG && BR_PUB_COALESCED) lds[Y.L.wk + j] = s;
-                else if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, s, epoch);
+                else if (TG) bb_gran_st(S.grow + (long long)cx.block * KS + j, s, epoch);
                 else bb_st<true>(S.prow + (long long)cx.block * KK + j, s);
             }
         }
         if (!(TG && BR_PUB_COALESCED)) for (int j = M.K + tid; j < KK; j += cx.nthr) {
-            if (TG) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch);
+            if (TG) bb_gran_st(S.grow + (long long)cx.block * KS + j, lds[Y.L.wk + j], epoch);
             else bb_st<true>(S.prow + (long long)cx.block * KK + j, lds[Y.L.wk + j]);
         }
     }
@@ -919,13 +920,13 @@ BB_DEV void br_row_publish(BBCtx& cx, const DevModel& M, const DevState& S, cons
             // read, from its leader's entry of this launch, that both run on the same XCC, and for good if they do not.
             int* li = (int*)(lds + Y.L.misc);
             BB_PASS(cx, tid) {
-                if (BR_ROW_L2 && li[4] > 0) { for (int j = tid; j < KK; j += cx.nthr) bb_gran_st_l2(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch); }
-                else for (int j = tid; j < KK; j += cx.nthr) bb_gran_st(S.grow + (long long)cx.block * KK + j, lds[Y.L.wk + j], epoch);
+                if (BR_ROW_L2 && li[4] > 0) { for (int j = tid; j < KK; j += cx.nthr) bb_gran_st_l2(S.grow + (long long)cx.block * KS + j, lds[Y.L.wk + j], epoch); }
+                else for (int j = tid; j < KK; j += cx.nthr) bb_gran_st(S.grow + (long long)cx.block * KS + j, lds[Y.L.wk + j], epoch);
                 if (BR_ROW_L2 && tid == 0 && li[4] == 0) {
                     int g = cx.block;
                     while (g >= li[7]) g -= li[7];          // (at most 31 rounds, the first steps of a launch only)
                     const unsigned long long v = bb_get_word64(S.xtab + g);
-                    if ((unsigned)(v >> 32) == (unsigned)li[6]) li[4] = (int)(unsigned)v == li[5] ? 1 : -1;
+                    if ((unsigned)(v >> 32) == (unsigned)li[6]) { li[4] = (int)(unsigned)v == li[5] ? 1 : -1; S.xsel[cx.block] = li[4]; }
                 }
             }
         }

@@ -88,8 +88,9 @@ struct DevState {
     unsigned *hstatus;                // host-mapped status words the host reads after a run without a copy: [0] timeout, [1] non-finite state
     double *prow;                     // [nblk][K + 2 nt1] rows of the tiles (persistent launch)
     double *xrow;                     // [2][8][K + 2 nt1] group rows, double-buffered by step parity
-    struct bb_gran *grow, *gxrow;     // k_res on one GPU: the same rows as self-validating 16-byte entries (bb_persist.h, BR_TG): [nblk][K + 2 nt1], [2][16][K + 2 nt1]
+    struct bb_gran *grow, *gxrow;     // k_res on one GPU: the same rows as self-validating 16-byte entries (bb_persist.h, BR_TG): [nblk][bb_row_stride(K + 2 nt1)], [2][16][K + 2 nt1]
     unsigned *rdy;                    // [32 * (nblk + 16)] ready words, one 128-B line each: tiles, then [2][8] groups
+    int *xsel;                        // [nblk + 8] what each tile of the last resident launch decided about its row stores: 1 plain (same XCD as its leader), -1 write-through, 0 not decided
     unsigned long long *xtab;         // [BB_NG_MAX] k_res / k_stream: where the group leaders run -- {launch tag << 32 | XCC id}, written by every leader at the start of
                                       //   a launch; a member whose own XCC id is the leader's stores its row with plain stores (br_row_publish)
     const double *segtab;             // k_res / k_stream: the tiles' segment tables, built on the host (bb_engine.hip, host_tables): [tiles][segtab_stride] doubles,
@@ -115,6 +116,7 @@ struct RunArgs {
     unsigned xepoch0;                 // base of the ready / inbox words of the resident launch: they carry base + step + 1 and only ever grow (bb_persist.h)
     unsigned spin_limit;              // polls of one ready word before a resident launch gives up (the first launch of a sharded run gets more)
     unsigned launch_tag;              // counts the handle's resident launches (never 0): what a launch's entries in DevState.xtab carry
+    int row_l2;                       // 1: tiles on their group leader's XCD store their row with plain stores (BB_TUNE_ROW_L2=0 turns it off)
     int nblk;                         // blocks of the barcode grid
     int nblk_alloc;                   // tiles the exchange / stamp buffers were sized for (+ 8)
     int ng;                           // groups of the exchange's first hop (8; k_res on one GPU: 16 where the tile has the threads for it)

@@ -164,6 +164,10 @@ typedef struct bb_stats {
     int64_t device_bytes;      /* device memory this handle allocated (a multi-device handle: all its shards)          */
     int64_t window_row;        /* entries of one row of the TruncatedADAGrad window: n_latents rounded up to 8 on a
                                   whole-problem handle; a shard keeps only the latents it updates (folded rows)        */
+    int32_t rows_same_xcd;     /* k_res / k_stream: tiles of the last launch that found themselves on their exchange group
+                                  leader's XCD and stored their row through the L2 they share (of n_blocks; 0 with
+                                  BB_TUNE_ROW_L2=0 in the environment, which keeps every row store write-through)        */
+    int32_t reserved0;
 } bb_stats;
 
 const char* bb_version(void);

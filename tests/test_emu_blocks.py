@@ -89,6 +89,29 @@ def test_owner_computes_launch_equals_two_kernel(emu_lib, name):
     c.case_persistent_equals_two_kernel(emu_lib, name, expect_kernel=2)
 
 
+@pytest.mark.parametrize("name", ["fitness_T6", "genotype_runs"])
+def test_same_xcd_row_stores_switch(emu_lib, monkeypatch, name):
+    """round 4: a tile on its exchange group leader's XCD stores its row with plain stores (br_row_publish); BB_TUNE_ROW_L2=0 keeps every row
+    store write-through.  The emulation has one 'XCD': every tile decides for plain stores once it has read its leader's entry of the launch
+    (bb_stats.rows_same_xcd), none with the switch off, and the runs agree bit for bit."""
+    from conftest import make_engine
+    monkeypatch.setenv("BB_TUNE_NB", "24" if name == "genotype_runs" else "8")
+    monkeypatch.setenv("BB_TUNE_NTHR", "512")
+    sp = c.synth(name, seed=4)
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("BB_TUNE_ROW_L2", sw)
+        with make_engine(sp, emu_lib, seed=5, window=4, launch_mode=2) as e:
+            st = e.stats()
+            assert st["resident_kernel"] == 2 and st["rows_same_xcd"] == 0
+            e.run(3)
+            e.run(3)
+            st = e.stats()
+            assert st["rows_same_xcd"] == (st["n_blocks"] if sw == "1" else 0), st
+            outs.append(e.get_params())
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
 @pytest.mark.parametrize("name", ["fitness_T6", "multienv_T8", "replicate_R3", "multienv_replicate_T6", "genotype_runs"])
 def test_host_built_tables_equal_the_kernels_own(emu_lib, monkeypatch, name):
     """The tiles' segment tables and the LDS descriptor tables come from the host (bb_engine.hip, host_tables); BB_NO_HOST_TABLES=1

@@ -228,6 +228,32 @@ def test_runs_are_bit_reproducible(hip_lib, mode):
     assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
 
 
+@pytest.mark.parametrize("workload", ["C2", "C5_one_gpu"])
+def test_same_xcd_row_stores_change_nothing_but_the_way(hip_lib, monkeypatch, workload):
+    """round 4: a tile that finds itself on its exchange group leader's XCD stores its row through the L2 they share (plain stores) instead of
+    writing it through; the entries validate themselves either way, so the run with the switch off (BB_TUNE_ROW_L2=0) must give the same bits --
+    at full size, k_res (C2) and k_stream (C5 on one GPU), over two launches (every launch decides again).  bb_stats.rows_same_xcd says how many
+    tiles took the short way: none with the switch off; with it on the number depends on where the dispatcher put the tiles (all of them on
+    the boxes this was developed on), so only its range is asserted."""
+    from conftest import make_engine
+    from barbay_jl_amd import synth
+    from oracle import port
+    wl = synth.fitness_normal(50_000, 8, 42) if workload == "C2" else synth.genotype_fitness_normal()
+    sp = port.spec_from_workload(wl)
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("BB_TUNE_ROW_L2", sw)
+        with make_engine(sp, hip_lib, seed=42, launch_mode=2) as e:
+            assert e.stats()["resident_kernel"] == (2 if workload == "C2" else 3)
+            e.run(120)
+            e.run(60)
+            st = e.stats()
+            print(f"{workload}: BB_TUNE_ROW_L2={sw}: {st['rows_same_xcd']} of {st['n_blocks']} tiles store their row through the shared L2")
+            assert (st["rows_same_xcd"] == 0) if sw == "0" else (0 <= st["rows_same_xcd"] <= st["n_blocks"])
+            outs.append(e.get_params())
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
 @pytest.mark.parametrize("name", ["fitness_T2", "fitness_T4", "fitness_T6", "fitness_neutral_heavy", "multienv_T6", "multienv_T8",
                                   "replicate_T6", "replicate_R3", "multienv_replicate_T6", "multienv_replicate_R3"])
 def test_owner_computes_launch_equals_two_kernel(hip_lib, name):
