@@ -288,6 +288,7 @@ def main():
                        "resident_kernel": int(st.get("resident_kernel", 0)),
                        "kernel_instance": eng.kernel_name(),
                        "tiles_per_rank": int(st["n_blocks"]), "threads_per_tile": int(st["block_threads"]),
+                       "tiles_storing_their_row_through_their_leaders_l2": int(st["rows_same_xcd"]),
                        "optimizer": "TruncatedADAGrad(0.1, 40, 100)", "sharding": f"barcodes/{world}",
                        "collective": "none" if world == 1 else (
                            f"resident launch per rank; 8 group rows of {int(st['n_moments'])} + 2(T-1) f64 pushed into every rank's inbox over xGMI per step"
